@@ -1,0 +1,166 @@
+/*
+ * ivl_hip.h -- C ABI of libivl_hip.so: MI355X (gfx950 / CDNA4) kernels for the
+ * InfiniteVL hybrid-attention hot path (Gated DeltaNet + sliding-window attention).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one
+ * operator the reference reaches through a third-party CUDA/Triton package; the
+ * reference call site it serves is cited as `std:<line>` =
+ * infinitevl/infinitevl_standard/modeling_infinitevl.py and `fla:` =
+ * src/llamafactory/model/fla/ (vendored snapshot of flash-linear-attention).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *     the library never allocates, frees, synchronises or branches on device data on the
+ *     host, so every call is hipGraph-capturable (SURVEY.md section 8b "Threading / streams").
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - layouts are the reference's time-major ones: q,k [B,T,H,K], v,o [B,T,H,V],
+ *     g,beta [B,T,H], recurrent state [B,H,K,V]; bf16 activations, fp32 g.
+ *   - return value: 0 = ok, negative = error code below; never throws, never exits.
+ *     ivl_last_error() returns a thread-local human-readable message for the last failure.
+ */
+#ifndef IVL_HIP_H
+#define IVL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVL_ABI_VERSION 1
+
+/* element type codes for the arguments that accept more than one */
+#define IVL_BF16 0
+#define IVL_F16 1
+#define IVL_F32 2
+
+/* error codes */
+#define IVL_OK 0
+#define IVL_ERR_INVALID_ARG (-1)   /* NULL pointer / non-positive size / bad dtype code        */
+#define IVL_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels are built for             */
+#define IVL_ERR_WORKSPACE (-3)     /* workspace too small (see the *_workspace_bytes helpers)  */
+#define IVL_ERR_LAUNCH (-4)        /* hipLaunch / hipGetLastError failure                      */
+
+int ivl_abi_version(void);
+const char* ivl_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gated DeltaNet, token-recurrent form.
+ * Replaces fla.ops.gated_delta_rule.fused_recurrent_gated_delta_rule
+ *   (call site std:1309-1320; kernel fla:ops/gated_delta_rule/fused_recurrent.py:21-112).
+ * Per token: S *= exp(g); d = beta*(v - S^T k); S += k d^T; o = S^T (q*scale); l2norm(q), l2norm(k)
+ * first when use_qk_l2norm != 0 (eps 1e-6, result rounded to bf16 like fla's l2norm_fwd).
+ * h0 (may be NULL = zeros) and ht (may be NULL = not stored) are [B,H,K,V] in h0_dtype/ht_dtype
+ * (IVL_F32 or IVL_BF16); ht may alias h0 (in-place state update: each element is read once, then
+ * written once by the same thread).  Requires K == 128, V % 64 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                          void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                          int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gated DeltaNet, chunkwise form (chunk = 64 tokens).
+ * Replaces fla.ops.gated_delta_rule.chunk_gated_delta_rule (call site std:1297-1308;
+ *   fla:ops/gated_delta_rule/chunk.py:18-71 = l2norm + cumsum + WY transform + state scan + output,
+ *   kernels K1-K6 of SURVEY.md section 2.1) with two launches: a chunk-parallel pre-pass and a fused
+ *   state-scan + output pass (the per-chunk state snapshots never reach HBM).
+ * `workspace` holds the pre-pass results; size from ivl_gdn_chunk_workspace_bytes.
+ * Requires K == 128, V == 256 (the InfiniteVL head shape), any T >= 1 (zero-padded last chunk).
+ * ------------------------------------------------------------------------------------------- */
+size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V);
+int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                      void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                      int B, int T, int H, int K, int V, float scale, int use_qk_l2norm,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gate math: beta = sigmoid(b) (bf16), g = -exp(A_log) * softplus(a + dt_bias) (fp32).
+ * Replaces the torch glue at std:1293-1294.  a,b bf16 [rows,H] (a_proj / b_proj outputs);
+ * A_log, dt_bias fp32 [H].
+ * ------------------------------------------------------------------------------------------- */
+int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const float* dt_bias,
+                     float* g, void* beta, int rows, int H, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Causal depthwise short convolution (+ optional SiLU) with state carry-in.
+ * Replaces fla.modules.ShortConvolution.forward / .step (call sites std:1263-1280;
+ *   fla:modules/convolution.py:195-293; CUDA ext causal_conv1d_fn / causal_conv1d_update).
+ * x,y bf16 [B,T,D]; weight bf16 [D,W] (W == 4); state [B,D,W] bf16 = last W raw inputs, newest
+ * last.  state_in == NULL means zero history; state_out == NULL means "do not store";
+ * state_out may alias state_in.  T == 1 is the decode step.  D % 8 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,
+                       int B, int T, int D, int W, int apply_silu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y = rmsnorm(x) * weight * gate * sigmoid(gate), rows of N == 256, statistics in fp32.
+ * Replaces fla.modules.FusedRMSNormGated.forward (call site std:1338;
+ *   fla:modules/fused_norm_gate.py:27-95).  x, gate, y bf16 [rows,N]; weight bf16 [N].
+ * ------------------------------------------------------------------------------------------- */
+int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
+                               int rows, int N, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multimodal rotary embedding applied in place to q [B,T,Hq,d] and k [B,T,Hkv,d] (bf16,
+ * contiguous time-major, i.e. the projection outputs before the reference's transpose).
+ * Replaces apply_multimodal_rotary_pos_emb (std:949-984, call site std:1057-1064).
+ * cos,sin bf16 [3,B,T,d] as produced by InfiniteVLRotaryEmbedding (std:918-930); sections s0,s1,s2
+ * (sum == d/2) pick the t/h/w table per channel block.  Products and the sum are each rounded to
+ * bf16 like the reference's eager bf16 arithmetic (bit-identical result).
+ * ------------------------------------------------------------------------------------------- */
+int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
+                  int B, int T, int Hq, int Hkv, int d, int s0, int s1, int s2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-window attention over (ring-buffer cache ++ new tokens), GQA, d == 128.
+ * Replaces ALL_ATTENTION_FUNCTIONS["flash_attention_2"] (call site std:1092-1108) together with
+ * the torch.cat cache maintenance of StaticSlidingWindowLayerPrealloc.update (std:126-173).
+ *
+ * Query row i of the call (absolute position pos+i) sees call-local keys
+ *     lo(i) = max(0, n_prev + i - window + 1) .. hi(i) = n_prev + i          (inclusive),
+ * where n_prev = min(cache_capacity, pos) cached keys precede the T new ones.
+ * Cached token with absolute position p lives in ring slot p % cache_capacity.
+ *
+ * All strides are in ELEMENTS.  k_new/v_new hold `T_new` >= T keys; when T_new > T the first
+ * T_new - T of them are additional already-seen keys in chronological order (this is how the
+ * operator-level call with a concatenated full_k/full_v is expressed: k_cache = NULL,
+ * T_new = S).  `pos` = tokens seen before this call; when pos_dev != NULL the kernels read the value
+ * from device memory instead (one hipGraph then serves every step).
+ * Workspace (split-KV partials): ivl_swa_workspace_bytes.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ivl_swa_args {
+  const void* q;            /* bf16, element (b,t,h,:) at q + b*q_sb + t*q_st + h*q_sh            */
+  const void* k_new;        /* bf16, element (b,j,hk,:) at k_new + b*kn_sb + j*kn_st + hk*kn_sh  */
+  const void* v_new;        /* same strides as k_new                                              */
+  const void* k_cache;      /* bf16 ring [B,Hkv,cache_capacity,d] contiguous, or NULL            */
+  const void* v_cache;
+  void* o;                  /* bf16 [B,T,Hq,d] contiguous                                          */
+  int64_t q_sb, q_st, q_sh;
+  int64_t kn_sb, kn_st, kn_sh;
+  int B, T, T_new, Hq, Hkv, d;
+  int cache_capacity;       /* C (= window-1 in the reference's cache); 0 when k_cache == NULL     */
+  int window;               /* W; <= 0 means plain causal                                          */
+  int64_t pos;              /* tokens seen before this call (ignored when pos_dev != NULL)         */
+  const int64_t* pos_dev;   /* optional device scalar                                              */
+  float scaling;
+  void* workspace;
+  size_t workspace_bytes;
+} ivl_swa_args;
+
+size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);
+int ivl_swa_fwd(const ivl_swa_args* args, void* stream);
+
+/* Append the T new tokens to the ring (slot (pos+t) % C) -- after ivl_swa_fwd of the same call.
+ * Replaces the tail copy-back of std:146-172.  k_new,v_new bf16 with the strides given. */
+int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
+                         void* k_cache, void* v_cache, int B, int T, int Hkv, int d, int cache_capacity,
+                         int64_t pos, const int64_t* pos_dev, void* stream);
+
+/* *counter += delta on the device (graph-replayable position bookkeeping). */
+int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVL_HIP_H */

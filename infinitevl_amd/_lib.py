@@ -1,0 +1,100 @@
+"""ctypes binding of libivl_hip.so (the C ABI declared in include/ivl_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C infinitevl_amd/csrc`.
+There is NO fallback: if the shared object is missing, importing an operator raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
+
+IVL_BF16, IVL_F16, IVL_F32 = 0, 1, 2
+IVL_OK = 0
+IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
+
+EXPORTED_SYMBOLS = (
+    "ivl_abi_version", "ivl_last_error",
+    "ivl_gdn_recurrent_fwd", "ivl_gdn_chunk_workspace_bytes", "ivl_gdn_chunk_fwd", "ivl_gdn_gate_fwd",
+    "ivl_short_conv_fwd", "ivl_rmsnorm_swish_gate_fwd", "ivl_mrope_fwd",
+    "ivl_swa_workspace_bytes", "ivl_swa_fwd", "ivl_swa_cache_append", "ivl_counter_add",
+)
+
+
+class SwaArgs(Structure):
+    """struct ivl_swa_args (include/ivl_hip.h)."""
+    _fields_ = [
+        ("q", c_void_p), ("k_new", c_void_p), ("v_new", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p),
+        ("o", c_void_p),
+        ("q_sb", c_int64), ("q_st", c_int64), ("q_sh", c_int64),
+        ("kn_sb", c_int64), ("kn_st", c_int64), ("kn_sh", c_int64),
+        ("B", c_int), ("T", c_int), ("T_new", c_int), ("Hq", c_int), ("Hkv", c_int), ("d", c_int),
+        ("cache_capacity", c_int), ("window", c_int),
+        ("pos", c_int64), ("pos_dev", c_void_p),
+        ("scaling", c_float),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+    ]
+
+
+class IvlError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libivl_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared object once and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found. The MI355X kernels are mandatory (there is no CPU or PyTorch fallback): "
+            "build them with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C infinitevl_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i, f, sz, i64 = c_void_p, c_int, c_float, c_size_t, c_int64
+    lib.ivl_abi_version.restype = i
+    lib.ivl_abi_version.argtypes = []
+    lib.ivl_last_error.restype = c_char_p
+    lib.ivl_last_error.argtypes = []
+    lib.ivl_gdn_recurrent_fwd.restype = i
+    lib.ivl_gdn_recurrent_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, vp]
+    lib.ivl_gdn_chunk_workspace_bytes.restype = sz
+    lib.ivl_gdn_chunk_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.ivl_gdn_chunk_fwd.restype = i
+    lib.ivl_gdn_chunk_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, vp, sz, vp]
+    lib.ivl_gdn_gate_fwd.restype = i
+    lib.ivl_gdn_gate_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp]
+    lib.ivl_short_conv_fwd.restype = i
+    lib.ivl_short_conv_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+    lib.ivl_rmsnorm_swish_gate_fwd.restype = i
+    lib.ivl_rmsnorm_swish_gate_fwd.argtypes = [vp, vp, vp, vp, i, i, f, vp]
+    lib.ivl_mrope_fwd.restype = i
+    lib.ivl_mrope_fwd.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
+    lib.ivl_swa_workspace_bytes.restype = sz
+    lib.ivl_swa_workspace_bytes.argtypes = [i, i, i, i]
+    lib.ivl_swa_fwd.restype = i
+    lib.ivl_swa_fwd.argtypes = [POINTER(SwaArgs), vp]
+    lib.ivl_swa_cache_append.restype = i
+    lib.ivl_swa_cache_append.argtypes = [vp, vp, i64, i64, i64, vp, vp, i, i, i, i, i, i64, vp, vp]
+    lib.ivl_counter_add.restype = i
+    lib.ivl_counter_add.argtypes = [vp, i64, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map a C status to the Python exception types the reference raises
+    (SURVEY.md section 8b "Error conventions")."""
+    if rc == IVL_OK:
+        return
+    msg = load().ivl_last_error().decode("utf-8", "replace")
+    if rc in (IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED):
+        raise ValueError(f"libivl_hip ({rc}): {msg}")
+    raise IvlError(rc, msg)

@@ -1,0 +1,599 @@
+// Gated DeltaNet, chunkwise form (chunk C = 64 tokens) for gfx950, K = 128, V = 256.
+//
+// Two launches (the reference uses six and materialises the per-chunk state h[B,NT,H,K,V] in HBM):
+//
+//  (1) gdn_chunk_prepare_kernel -- chunk-PARALLEL, one workgroup per (chunk, batch*head):
+//        l2norm(q), l2norm(k) -> bf16;  gamma = cumsum(g);  L = tril(bf16(beta k) k^T, -1) (MFMA bf16);
+//        Tw = (I+L)^-1 in fp32: 16x16 diagonal blocks by forward substitution, off-diagonal blocks by
+//        block elimination on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); Tu = Tw * e^{gamma_i-gamma_j};
+//        w = bf16(Tw) bf16(beta k),  u = bf16(Tu) bf16(beta v)  (MFMA bf16);
+//        A = tril((q k^T) * Gamma) -> bf16.
+//      It leaves in the workspace, per chunk, exactly the operands the serial pass needs, already decayed
+//      and laid out K-contiguous ("NT" operands) so that the scan issues plain 16-byte fragment loads:
+//        Wg[64][128] = bf16(w * e^gamma)   Qh[64][128] = q_hat     KdT[128][64] = bf16(k_hat * e^{gl-gamma})^T
+//        UT[256][64] = u^T                 Aqk[64][64]             eg[64] = e^gamma, egl = e^{gamma_last}
+//  (2) gdn_chunk_scan_kernel -- SERIAL over chunks, one workgroup per (32-column slab of V, batch*head):
+//        the fp32 state slab S[128x32] lives in MFMA accumulators (wave w owns rows 32w..32w+31);
+//        per chunk:  v_new = u - Wg S ;  o = scale((Qh S) * e^gamma + Aqk v_new) ;  S = egl S + KdT v_new
+//        with bf16 MFMA operands / fp32 accumulation at the reference's rounding points.  State and
+//        v_new cross waves through two small LDS tiles (S^T bf16, v_new^T bf16); nothing else leaves the CU.
+//
+// All matrix products are "NT" products on v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8(l>>5)..+7]
+// and B^T[j=l&31][k=8(l>>5)..+7] (16 contiguous bytes each), C[i=(r&3)+8(r>>2)+4(l>>5)][j=l&31].
+#include "ivl_common.h"
+
+namespace ivl {
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GC = 64;        // chunk length
+constexpr int GK = 128;       // key head dim
+constexpr int GV = 256;       // value head dim
+constexpr int G_BV = 32;      // state columns per scan workgroup
+constexpr int G_SEG_CHUNKS = 64;   // chunks per workspace segment (4096 tokens)
+
+// workspace record per (batch*head, chunk): byte offsets
+constexpr size_t WS_WG = 0;                       // bf16 [64][128]
+constexpr size_t WS_QH = WS_WG + GC * GK * 2;     // bf16 [64][128]
+constexpr size_t WS_KDT = WS_QH + GC * GK * 2;    // bf16 [128][64]
+constexpr size_t WS_UT = WS_KDT + GK * GC * 2;    // bf16 [256][64]
+constexpr size_t WS_AQK = WS_UT + GV * GC * 2;    // bf16 [64][64]
+constexpr size_t WS_EG = WS_AQK + GC * GC * 2;    // f32  [64]
+constexpr size_t WS_EGL = WS_EG + GC * 4;         // f32  [1] (+pad)
+constexpr size_t WS_STRIDE = WS_EGL + 256;        // 90624
+
+__device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) {
+  mfma_bf16x8 r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
+}
+__device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ==================================================================================================
+// (1) chunk-parallel pre-pass
+// ==================================================================================================
+// LDS map (bytes).  Row strides are padded so 16-byte fragment reads of 32 consecutive rows spread banks.
+constexpr int P_LDK = 136;                         // bf16 elements per row of kh/qh/kb/stage (272 B)
+constexpr int P_LDT = 72;                          // bf16 elements per row of kbT/vbT/TwB/TuB (144 B)
+constexpr int P_LDF = 65;                          // f32 elements per row of L / T
+constexpr int P_LDY = 33;
+constexpr int P_KH = 0;
+constexpr int P_QH = P_KH + GC * P_LDK * 2;        // later: TwB (kh region later: TuB)
+constexpr int P_KB = P_QH + GC * P_LDK * 2;        // later: output staging
+constexpr int P_KBT = P_KB + GC * P_LDK * 2;
+constexpr int P_VBT = P_KBT + GK * P_LDT * 2;
+constexpr int P_L = P_VBT + GV * P_LDT * 2;
+constexpr int P_T = P_L + GC * P_LDF * 4;
+constexpr int P_Y = P_T + GC * P_LDF * 4;
+constexpr int P_SM = P_Y + 32 * P_LDY * 4;         // gam[64], beta[64], eg[64]
+constexpr int P_BYTES = P_SM + 3 * GC * 4;
+constexpr int P_TWB = P_QH;                        // qh is dead after S2
+constexpr int P_TUB = P_KH;                        // kh is dead after S2
+static_assert(P_BYTES <= 160 * 1024, "pre-pass LDS budget");
+static_assert(GC * P_LDT * 2 <= GC * P_LDK * 2, "TwB / TuB must fit in the qh / kh regions");
+
+// fp32 16x16 tile product on v_mfma_f32_16x16x4_f32 from LDS operands: acc += A[a_r0.., a_c0..] * B[b_r0.., b_c0..]
+__device__ __forceinline__ f32x4 tile16_f32(f32x4 acc, const float* A, int lda, int a_r0, int a_c0,
+                                            const float* Bm, int ldb, int b_r0, int b_c0, int K, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+  for (int kk = 0; kk < K; kk += 4) {
+    const float a = A[(a_r0 + i) * lda + a_c0 + kk + kq];
+    const float b = Bm[(b_r0 + kk + kq) * ldb + b_c0 + i];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ void store16_f32(float* Cm, int ldc, int r0, int c0, f32x4 acc, float sign, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Cm[(r0 + 4 * g + r) * ldc + c0 + j] = sign * acc[r];
+}
+
+__global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const float* __restrict__ g, const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws,
+    int T, int H, int t_seg0, int nt_seg, int l2norm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* s_kh = (bf16_t*)(smem + P_KH);
+  bf16_t* s_qh = (bf16_t*)(smem + P_QH);
+  bf16_t* s_kb = (bf16_t*)(smem + P_KB);
+  bf16_t* s_kbT = (bf16_t*)(smem + P_KBT);
+  bf16_t* s_vbT = (bf16_t*)(smem + P_VBT);
+  float* s_L = (float*)(smem + P_L);
+  float* s_T = (float*)(smem + P_T);
+  float* s_Y = (float*)(smem + P_Y);
+  float* s_gam = (float*)(smem + P_SM);
+  float* s_beta = s_gam + GC;
+  float* s_eg = s_beta + GC;
+  bf16_t* s_twb = (bf16_t*)(smem + P_TWB);
+  bf16_t* s_tub = (bf16_t*)(smem + P_TUB);
+  bf16_t* s_stage = (bf16_t*)(smem + P_KB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int ci = blockIdx.x;                  // chunk within the segment
+  const int bh = blockIdx.y;
+  const int b = bh / H, h = bh % H;
+  const int t0 = t_seg0 + ci * GC;            // first token of the chunk
+  const int nvalid = min(GC, T - t0);
+  unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * WS_STRIDE;
+
+  // ---- S0: g, beta; chunk-local inclusive cumsum (wave 0) -------------------------------------
+  if (wave == 0) {
+    float gv = 0.f, bv = 0.f;
+    if (lane < nvalid) {
+      const size_t tok = ((size_t)b * T + t0 + lane) * H + h;
+      gv = g[tok];
+      bv = bf2f(beta[tok]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(gv, o, 64);
+      if (lane >= o) gv += up;
+    }
+    s_gam[lane] = gv;
+    s_beta[lane] = bv;
+    const float e = __expf(gv);
+    s_eg[lane] = e;
+    ((float*)(rec + WS_EG))[lane] = e;
+    const float gl = __shfl(gv, nvalid - 1, 64);     // gamma at the last VALID token
+    if (lane == 0) *(float*)(rec + WS_EGL) = __expf(gl);
+  }
+  // zero T (upper blocks stay zero)
+  for (int i = tid; i < GC * P_LDF; i += 256) s_T[i] = 0.f;
+  __syncthreads();
+  const float gam_last = s_gam[nvalid - 1];
+
+  // ---- S1: load q,k (4 rows x 8 cols per thread), l2norm, bf16; kh,qh,kb row-major, kbT transposed,
+  //          Qh -> global, KdT -> global ------------------------------------------------------------
+  {
+    const int oct = tid & 15, rg = tid >> 4;       // 16 column octets x 16 row groups of 4 rows
+    float kf[4][8], qf[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * rg + r;
+      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, qv = u32x4{0u, 0u, 0u, 0u};
+      if (row < nvalid) {
+        const size_t tok = ((size_t)b * T + t0 + row) * H + h;
+        kv = *(const u32x4*)(k + tok * GK + 8 * oct);
+        qv = *(const u32x4*)(q + tok * GK + 8 * oct);
+      }
+      kf[r][0] = bflo(kv.x); kf[r][1] = bfhi(kv.x); kf[r][2] = bflo(kv.y); kf[r][3] = bfhi(kv.y);
+      kf[r][4] = bflo(kv.z); kf[r][5] = bfhi(kv.z); kf[r][6] = bflo(kv.w); kf[r][7] = bfhi(kv.w);
+      qf[r][0] = bflo(qv.x); qf[r][1] = bfhi(qv.x); qf[r][2] = bflo(qv.y); qf[r][3] = bfhi(qv.y);
+      qf[r][4] = bflo(qv.z); qf[r][5] = bfhi(qv.z); qf[r][6] = bflo(qv.w); qf[r][7] = bfhi(qv.w);
+      if (l2norm) {
+        float ks = 0.f, qs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { ks = fmaf(kf[r][c], kf[r][c], ks); qs = fmaf(qf[r][c], qf[r][c], qs); }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { ks += __shfl_xor(ks, o, 64); qs += __shfl_xor(qs, o, 64); }
+        const float rk = 1.0f / sqrtf(ks + 1e-6f), rq = 1.0f / sqrtf(qs + 1e-6f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { kf[r][c] = bf_round(kf[r][c] * rk); qf[r][c] = bf_round(qf[r][c] * rq); }
+      }
+    }
+    float kd[4][8], kbv[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * rg + r;
+      const float bt = s_beta[row];
+      const float dec = __expf(gam_last - s_gam[row]);
+      u32x4 w_kh, w_qh, w_kb;
+      unsigned int* pk = (unsigned int*)&w_kh;
+      unsigned int* pq = (unsigned int*)&w_qh;
+      unsigned int* pb = (unsigned int*)&w_kb;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        kbv[r][c] = bf_round(kf[r][c] * bt);
+        kd[r][c] = row < nvalid ? kf[r][c] * dec : 0.f;
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) {
+        pk[c2] = pack2bf(kf[r][2 * c2], kf[r][2 * c2 + 1]);
+        pq[c2] = pack2bf(qf[r][2 * c2], qf[r][2 * c2 + 1]);
+        pb[c2] = pack2bf(kbv[r][2 * c2], kbv[r][2 * c2 + 1]);
+      }
+      *(u32x4*)(s_kh + row * P_LDK + 8 * oct) = w_kh;
+      *(u32x4*)(s_qh + row * P_LDK + 8 * oct) = w_qh;
+      *(u32x4*)(s_kb + row * P_LDK + 8 * oct) = w_kb;
+      *(u32x4*)(rec + WS_QH + ((size_t)row * GK + 8 * oct) * 2) = w_qh;
+    }
+    // transposed copies: column (8 oct + c), rows 4rg..4rg+3  (8 bytes)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      u32x2 wb, wd;
+      wb.x = pack2bf(kbv[0][c], kbv[1][c]); wb.y = pack2bf(kbv[2][c], kbv[3][c]);
+      wd.x = pack2bf(kd[0][c], kd[1][c]);   wd.y = pack2bf(kd[2][c], kd[3][c]);
+      *(u32x2*)(s_kbT + (8 * oct + c) * P_LDT + 4 * rg) = wb;
+      *(u32x2*)(rec + WS_KDT + ((size_t)(8 * oct + c) * GC + 4 * rg) * 2) = wd;
+    }
+  }
+  // ---- S1b: v (8 rows x 8 cols per thread) -> vbT = bf16(beta v)^T -----------------------------
+  {
+    const int oct = tid & 31, rg = tid >> 5;       // 32 column octets x 8 row groups of 8 rows
+    float vf[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = 8 * rg + r;
+      u32x4 vv = u32x4{0u, 0u, 0u, 0u};
+      if (row < nvalid) {
+        const size_t tok = ((size_t)b * T + t0 + row) * H + h;
+        vv = *(const u32x4*)(v + tok * GV + 8 * oct);
+      }
+      const float bt = s_beta[row];
+      vf[r][0] = bflo(vv.x) * bt; vf[r][1] = bfhi(vv.x) * bt; vf[r][2] = bflo(vv.y) * bt; vf[r][3] = bfhi(vv.y) * bt;
+      vf[r][4] = bflo(vv.z) * bt; vf[r][5] = bfhi(vv.z) * bt; vf[r][6] = bflo(vv.w) * bt; vf[r][7] = bfhi(vv.w) * bt;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      u32x4 w;
+      w.x = pack2bf(vf[0][c], vf[1][c]); w.y = pack2bf(vf[2][c], vf[3][c]);
+      w.z = pack2bf(vf[4][c], vf[5][c]); w.w = pack2bf(vf[6][c], vf[7][c]);
+      *(u32x4*)(s_vbT + (8 * oct + c) * P_LDT + 8 * rg) = w;
+    }
+  }
+  __syncthreads();
+
+  // ---- S2: L = tril(kb kh^T, -1) -> s_L (fp32);  Aqk = tril((qh kh^T) * Gamma) -> global bf16 ------
+  //          wave w -> 32x32 tile (mi = w>>1, ni = w&1); tile (0,1) lies above the diagonal.
+  {
+    const int mi = wave >> 1, ni = wave & 1;
+    if (!(mi == 0 && ni == 1)) {
+      f32x16 accL, accA;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accL[r] = 0.f; accA[r] = 0.f; }
+      const bf16_t* arow_kb = s_kb + (32 * mi + l31) * P_LDK + 8 * hi;
+      const bf16_t* arow_qh = s_qh + (32 * mi + l31) * P_LDK + 8 * hi;
+      const bf16_t* brow = s_kh + (32 * ni + l31) * P_LDK + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < GK / 16; ++ks) {
+        const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
+        const u32x4 a1 = *(const u32x4*)(arow_kb + 16 * ks);
+        const u32x4 a2 = *(const u32x4*)(arow_qh + 16 * ks);
+        accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(a1), mf(bfr), accL, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(a2), mf(bfr), accA, 0, 0, 0);
+      }
+      const int j = 32 * ni + l31;
+      const float gj = s_gam[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * mi + crow32(r, hi);
+        s_L[i * P_LDF + j] = i > j ? accL[r] : 0.f;
+        const float a = i >= j ? accA[r] * __expf(s_gam[i] - gj) : 0.f;
+        ((bf16_t*)(rec + WS_AQK))[i * GC + j] = f2bf(a);
+      }
+    } else {
+      // zero the strictly-upper tile of L and Aqk
+      const int j = 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = crow32(r, hi);
+        s_L[i * P_LDF + j] = 0.f;
+        ((bf16_t*)(rec + WS_AQK))[i * GC + j] = 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S3: T = (I + L)^-1 ----------------------------------------------------------------------
+  // (a) diagonal 16x16 blocks by forward substitution: wave w -> block w, lane c<16 -> column c.
+  if (lane < 16) {
+    const int r0 = 16 * wave, c = lane;
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = (i == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj)
+        if (jj < i) s = fmaf(-s_L[(r0 + i) * P_LDF + r0 + jj], x[jj], s);
+      x[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_T[(r0 + i) * P_LDF + r0 + c] = x[i];
+  }
+  __syncthreads();
+  // (b) 16->32: X21 = -X22 (L21 X11) for block pairs (0,1) [wave 0] and (2,3) [wave 1]
+  if (wave < 2) {
+    const int base = 32 * wave;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = tile16_f32(acc, s_L, P_LDF, base + 16, base, s_T, P_LDF, base, base, 16, lane);
+    store16_f32(s_Y, P_LDY, 16 * wave, 0, acc, 1.f, lane);
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int base = 32 * wave;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = tile16_f32(acc, s_T, P_LDF, base + 16, base + 16, s_Y, P_LDY, 16 * wave, 0, 16, lane);
+    store16_f32(s_T, P_LDF, base + 16, base, acc, -1.f, lane);
+  }
+  __syncthreads();
+  // (c) 32->64: T21 = -T22 (L21 T11), 32x32 blocks; wave w -> 16x16 tile (w>>1, w&1)
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = tile16_f32(acc, s_L, P_LDF, 32 + 16 * ti, 0, s_T, P_LDF, 0, 16 * tj, 32, lane);
+    store16_f32(s_Y, P_LDY, 16 * ti, 16 * tj, acc, 1.f, lane);
+  }
+  __syncthreads();
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = tile16_f32(acc, s_T, P_LDF, 32 + 16 * ti, 32, s_Y, P_LDY, 0, 16 * tj, 32, lane);
+    store16_f32(s_T, P_LDF, 32 + 16 * ti, 16 * tj, acc, -1.f, lane);
+  }
+  __syncthreads();
+
+  // ---- S4: Tw, Tu = Tw * e^{gamma_i - gamma_j} -> bf16 (into the dead qh / kh regions) -----------
+  for (int idx = tid; idx < GC * GC; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    const float t = s_T[i * P_LDF + j];
+    s_twb[i * P_LDT + j] = f2bf(t);
+    s_tub[i * P_LDT + j] = f2bf(i >= j ? t * __expf(s_gam[i] - s_gam[j]) : 0.f);
+  }
+  __syncthreads();
+
+  // ---- S5: w = Tw kb  (64x64 . 64x128): wave w -> columns 32w..32w+31, both row tiles ------------
+  {
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    const bf16_t* brow = s_kbT + (32 * wave + l31) * P_LDT + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < GC / 16; ++ks) {
+      const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const u32x4 afr = *(const u32x4*)(s_twb + (32 * mi + l31) * P_LDT + 8 * hi + 16 * ks);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr), mf(bfr), acc[mi], 0, 0, 0);
+      }
+    }
+    // Wg = bf16(bf16(w) * e^gamma_i) staged row-major in the (dead) kb region
+    __syncthreads();     // every wave is done reading s_kb (S2) long ago; kbT/twb are separate regions
+    const int j = 32 * wave + l31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * mi + crow32(r, hi);
+        s_stage[i * P_LDK + j] = f2bf(bf_round(acc[mi][r]) * s_eg[i]);
+      }
+  }
+  __syncthreads();
+  // coalesced copy-out of Wg (64 rows x 256 B)
+  for (int idx = tid; idx < GC * (GK / 8); idx += 256) {
+    const int row = idx >> 4, ch = idx & 15;
+    *(u32x4*)(rec + WS_WG + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_stage + row * P_LDK + 8 * ch);
+  }
+
+  // ---- S6: u = Tu vb  (64x64 . 64x256): wave w -> columns 64w..64w+63 ; UT[col][time] to global --
+  {
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+      const int col = 64 * wave + 32 * nj + l31;
+      const bf16_t* brow = s_vbT + col * P_LDT + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < GC / 16; ++ks) {
+        const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const u32x4 afr = *(const u32x4*)(s_tub + (32 * mi + l31) * P_LDT + 8 * hi + 16 * ks);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr), mf(bfr), acc[mi], 0, 0, 0);
+        }
+      }
+      bf16_t* ut = (bf16_t*)(rec + WS_UT) + (size_t)col * GC;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          u32x2 w;
+          w.x = pack2bf(acc[mi][4 * r4 + 0], acc[mi][4 * r4 + 1]);
+          w.y = pack2bf(acc[mi][4 * r4 + 2], acc[mi][4 * r4 + 3]);
+          *(u32x2*)(ut + 32 * mi + 8 * r4 + 4 * hi) = w;      // times 32mi + 8r4 + 4hi + 0..3
+        }
+    }
+  }
+}
+
+// ==================================================================================================
+// (2) serial scan + output
+// ==================================================================================================
+constexpr int S_LDS = 136;     // bf16 per row of S^T  [32 cols][128 k]   (272 B)
+constexpr int S_LDV = 72;      // bf16 per row of v_new^T [32 cols][64 t] (144 B)
+
+__global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
+    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
+    const void* h0, int h0_dtype, void* ht, int ht_dtype,
+    int T, int H, int t_seg0, int nt_seg, float scale) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_st[G_BV * S_LDS];
+  __shared__ __attribute__((aligned(16))) bf16_t s_vn[G_BV * S_LDV];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int v0 = blockIdx.x * G_BV;
+  const int bh = blockIdx.y;
+  const int b = bh / H, h = bh % H;
+  const bool is_p = wave < 2;                 // waves 0,1: v_new rows 32*wave.. ; waves 2,3: output rows 32*(wave-2)..
+  const int mrow0 = 32 * (wave & 1);
+
+  // state slab rows 32*wave + crow32(r,hi), column v0 + l31
+  f32x16 S;
+  {
+    const size_t base = ((size_t)bh * GK + 32 * wave) * GV + v0 + l31;
+    if (h0 != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = load_state(h0, base + (size_t)crow32(r, hi) * GV, h0_dtype);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    }
+  }
+
+  for (int ci = 0; ci < nt_seg; ++ci) {
+    const unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * WS_STRIDE;
+    const int tc0 = t_seg0 + ci * GC;
+
+    // ---- operand fragments of this chunk (global, L2-resident; independent of the state) --------
+    u32x4 afr[8];                                   // Wg (waves 0,1) or Qh (waves 2,3): rows mrow0 + l31
+    {
+      const bf16_t* ap = (const bf16_t*)(rec + (is_p ? WS_WG : WS_QH)) + (size_t)(mrow0 + l31) * GK + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) afr[ks] = *(const u32x4*)(ap + 16 * ks);
+    }
+    u32x4 kdfr[4];                                  // KdT rows 32*wave + l31 (state rows of this wave)
+    {
+      const bf16_t* kp = (const bf16_t*)(rec + WS_KDT) + (size_t)(32 * wave + l31) * GC + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kdfr[ks] = *(const u32x4*)(kp + 16 * ks);
+    }
+    u32x4 aqfr[4];                                  // Aqk rows mrow0 + l31 (waves 2,3)
+    u32x2 ufr[4];                                   // UT[v0 + l31][mrow0 + 8 r4 + 4 hi + 0..3] (waves 0,1)
+    f32x4 egv[4];                                   // e^gamma for rows mrow0 + 8 r4 + 4 hi + 0..3 (waves 2,3)
+    if (is_p) {
+      const bf16_t* up = (const bf16_t*)(rec + WS_UT) + (size_t)(v0 + l31) * GC + mrow0 + 4 * hi;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) ufr[r4] = *(const u32x2*)(up + 8 * r4);
+    } else {
+      const bf16_t* qp = (const bf16_t*)(rec + WS_AQK) + (size_t)(mrow0 + l31) * GC + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) aqfr[ks] = *(const u32x4*)(qp + 16 * ks);
+      const float* ep = (const float*)(rec + WS_EG) + mrow0 + 4 * hi;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) egv[r4] = *(const f32x4*)(ep + 8 * r4);
+    }
+    const float egl = *(const float*)(rec + WS_EGL);
+
+    // ---- (i) publish the state slab as bf16 S^T[col][k] -----------------------------------------
+    __syncthreads();          // previous chunk's readers of s_st / s_vn are done
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      u32x2 w;
+      w.x = pack2bf(S[4 * r4 + 0], S[4 * r4 + 1]);
+      w.y = pack2bf(S[4 * r4 + 2], S[4 * r4 + 3]);
+      *(u32x2*)(s_st + l31 * S_LDS + 32 * wave + 8 * r4 + 4 * hi) = w;
+    }
+    __syncthreads();
+
+    // ---- (ii) [Wg ; Qh] S : every wave one 32x32 tile over K = 128 --------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const bf16_t* bp = s_st + l31 * S_LDS + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 bfr = *(const u32x4*)(bp + 16 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr[ks]), mf(bfr), acc, 0, 0, 0);
+      }
+    }
+    if (is_p) {
+      // v_new = u - Wg S  -> bf16 -> v_new^T[col][time]
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float u0 = bflo(ufr[r4].x), u1 = bfhi(ufr[r4].x), u2 = bflo(ufr[r4].y), u3 = bfhi(ufr[r4].y);
+        u32x2 w;
+        w.x = pack2bf(u0 - acc[4 * r4 + 0], u1 - acc[4 * r4 + 1]);
+        w.y = pack2bf(u2 - acc[4 * r4 + 2], u3 - acc[4 * r4 + 3]);
+        *(u32x2*)(s_vn + l31 * S_LDV + mrow0 + 8 * r4 + 4 * hi) = w;
+      }
+    } else {
+      // (Qh S) * e^gamma_i
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * r4 + i] *= egv[r4][i];
+    }
+    __syncthreads();
+
+    // ---- (iii) output rows (waves 2,3): + Aqk v_new ; state update (all waves) ----------------------
+    const bf16_t* vp = s_vn + l31 * S_LDV + 8 * hi;
+    u32x4 vfr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vfr[ks] = *(const u32x4*)(vp + 16 * ks);
+    if (!is_p) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(aqfr[ks]), mf(vfr[ks]), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = tc0 + mrow0 + crow32(r, hi);
+        if (t < T) o[(((size_t)b * T + t) * H + h) * GV + v0 + l31] = f2bf(acc[r] * scale);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] *= egl;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(kdfr[ks]), mf(vfr[ks]), S, 0, 0, 0);
+  }
+
+  if (ht != nullptr) {
+    const size_t base = ((size_t)bh * GK + 32 * wave) * GV + v0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) store_state(ht, base + (size_t)crow32(r, hi) * GV, ht_dtype, S[r]);
+  }
+}
+
+}  // namespace ivl
+
+using namespace ivl;
+
+static inline int seg_chunks(int NT) { return NT < G_SEG_CHUNKS ? NT : G_SEG_CHUNKS; }
+
+extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V) {
+  if (B <= 0 || T <= 0 || H <= 0 || K != GK || V != GV) return 0;
+  const int NT = (T + GC - 1) / GC;
+  size_t bytes = (size_t)B * H * seg_chunks(NT) * WS_STRIDE;
+  if (NT > G_SEG_CHUNKS) bytes += (size_t)B * H * GK * GV * sizeof(float);   // fp32 state carried between segments
+  return bytes;
+}
+
+extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                                 void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                                 int B, int T, int H, int K, int V, float scale, int use_qk_l2norm,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  IVL_REQUIRE(q && k && v && g && beta && o, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: NULL pointer");
+  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
+  IVL_REQUIRE(K == GK && V == GV, IVL_ERR_UNSUPPORTED, "ivl_gdn_chunk_fwd: built for K=128,V=256 (got %d,%d)", K, V);
+  IVL_REQUIRE((h0 == nullptr || h0_dtype == IVL_F32 || h0_dtype == IVL_BF16) &&
+              (ht == nullptr || ht_dtype == IVL_F32 || ht_dtype == IVL_BF16),
+              IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: state dtype must be IVL_F32 or IVL_BF16");
+  const size_t need = ivl_gdn_chunk_workspace_bytes(B, T, H, K, V);
+  IVL_REQUIRE(workspace != nullptr && workspace_bytes >= need, IVL_ERR_WORKSPACE,
+              "ivl_gdn_chunk_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_BYTES);
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int NT = (T + GC - 1) / GC;
+  const int segc = seg_chunks(NT);
+  unsigned char* wsb = (unsigned char*)workspace;
+  float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * WS_STRIDE) : nullptr;
+  for (int c0 = 0; c0 < NT; c0 += segc) {
+    const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
+    const bool first = c0 == 0, last = c0 + nseg >= NT;
+    hipLaunchKernelGGL(gdn_chunk_prepare_kernel, dim3(nseg, B * H), dim3(256), P_BYTES, st,
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb,
+                       T, H, c0 * GC, nseg, use_qk_l2norm);
+    int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
+    if (rc != IVL_OK) return rc;
+    const void* hin = first ? h0 : (const void*)carry;
+    const int hin_dt = first ? h0_dtype : IVL_F32;
+    void* hout = last ? ht : (void*)carry;
+    const int hout_dt = last ? ht_dtype : IVL_F32;
+    hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(GV / G_BV, B * H), dim3(256), 0, st,
+                       (const unsigned char*)wsb, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
+    rc = check_launch("ivl_gdn_chunk_fwd(scan)");
+    if (rc != IVL_OK) return rc;
+  }
+  return IVL_OK;
+}

@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 kernels of libivl_hip.so.
+// Written for CDNA4 only: 64-lane wavefronts, MFMA 16x16x32 / 32x32x16 bf16, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ivl_hip.h"
+
+namespace ivl {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned int)x) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float h2f_bits(unsigned short h) {
+  _Float16 x;
+  __builtin_memcpy(&x, &h, 2);
+  return (float)x;
+}
+
+// state element load/store in IVL_F32 / IVL_BF16 (wave-uniform dtype)
+__device__ __forceinline__ float load_state(const void* p, size_t idx, int dtype) {
+  return dtype == IVL_F32 ? ((const float*)p)[idx] : bf2f(((const bf16_t*)p)[idx]);
+}
+__device__ __forceinline__ void store_state(void* p, size_t idx, int dtype, float v) {
+  if (dtype == IVL_F32) ((float*)p)[idx] = v;
+  else ((bf16_t*)p)[idx] = f2bf(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- host side -------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define IVL_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      ivl::set_error(__VA_ARGS__);          \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+}  // namespace ivl

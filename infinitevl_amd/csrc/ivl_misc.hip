@@ -1,0 +1,317 @@
+// Bandwidth-bound kernels either side of the Gated DeltaNet / SWA kernels:
+// short causal conv (+SiLU, state carry-in), gated RMSNorm, gate math, M-RoPE, and the
+// device-side position counter.  All are HBM-bound: 16-byte vector loads, one pass.
+#include <stdarg.h>
+
+#include "ivl_common.h"
+
+namespace ivl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return IVL_ERR_LAUNCH;
+  }
+  return IVL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// short conv: y[b,t,d] = act(sum_j w[d,j] * ext[t+1+j, d]), ext = concat(state_in^T (W rows), x).
+// One thread = 8 channels x TCH consecutive tokens; the thread of token-chunk 0 is the only reader
+// of state_in for its channels and also the writer of state_out, so state_out may alias state_in.
+// ------------------------------------------------------------------------------------------------
+constexpr int CONV_W = 4;
+constexpr int CONV_TCH = 8;
+
+__global__ __launch_bounds__(256) void short_conv_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* state_in,
+    bf16_t* __restrict__ y, bf16_t* state_out, int B, int T, int D, int apply_silu) {
+  const int DG = D / 8;
+  const int NCH = (T + CONV_TCH - 1) / CONV_TCH;
+  const long long total = (long long)B * NCH * DG;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int dg = (int)(idx % DG);
+    const int ch = (int)((idx / DG) % NCH);
+    const int b = (int)(idx / ((long long)DG * NCH));
+    const int d0 = dg * 8;
+    const int t0 = ch * CONV_TCH;
+
+    // weights: 8 channels x 4 taps
+    float wf[8][CONV_W];
+    {
+      const u32x4* wp = (const u32x4*)(w + (size_t)d0 * CONV_W);
+      u32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+      unsigned int ww[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                             w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        wf[c][0] = bflo(ww[2 * c]);
+        wf[c][1] = bfhi(ww[2 * c]);
+        wf[c][2] = bflo(ww[2 * c + 1]);
+        wf[c][3] = bfhi(ww[2 * c + 1]);
+      }
+    }
+    // history state for these 8 channels (only needed by chunk 0)
+    float st[8][CONV_W];
+    if (ch == 0) {
+      if (state_in != nullptr) {
+        const u32x4* sp = (const u32x4*)(state_in + ((size_t)b * D + d0) * CONV_W);
+        u32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+        unsigned int ss[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w,
+                               s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          st[c][0] = bflo(ss[2 * c]);
+          st[c][1] = bfhi(ss[2 * c]);
+          st[c][2] = bflo(ss[2 * c + 1]);
+          st[c][3] = bfhi(ss[2 * c + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int j = 0; j < CONV_W; ++j) st[c][j] = 0.f;
+      }
+    }
+    // sliding window of the last 3 inputs: win[k][c] = input at time (t0-3+k)
+    float win[3][8];
+    const bf16_t* xb = x + (size_t)b * T * D + d0;
+    if (ch == 0) {
+      // times -3,-2,-1 come from the carried state (newest last): state[...,1..3]
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) win[k][c] = st[c][k + 1];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        u32x4 v = *(const u32x4*)(xb + (size_t)(t0 - 3 + k) * D);
+        win[k][0] = bflo(v.x); win[k][1] = bfhi(v.x); win[k][2] = bflo(v.y); win[k][3] = bfhi(v.y);
+        win[k][4] = bflo(v.z); win[k][5] = bfhi(v.z); win[k][6] = bflo(v.w); win[k][7] = bfhi(v.w);
+      }
+    }
+    const int tend = min(t0 + CONV_TCH, T);
+    for (int t = t0; t < tend; ++t) {
+      u32x4 v = *(const u32x4*)(xb + (size_t)t * D);
+      float cur[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+      float out[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = wf[c][0] * win[0][c];
+        a = fmaf(wf[c][1], win[1][c], a);
+        a = fmaf(wf[c][2], win[2][c], a);
+        a = fmaf(wf[c][3], cur[c], a);
+        if (apply_silu) a = a * sigmoidf_(a);
+        out[c] = a;
+        win[0][c] = win[1][c];
+        win[1][c] = win[2][c];
+        win[2][c] = cur[c];
+      }
+      u32x4 o;
+      o.x = pack2bf(out[0], out[1]); o.y = pack2bf(out[2], out[3]);
+      o.z = pack2bf(out[4], out[5]); o.w = pack2bf(out[6], out[7]);
+      *(u32x4*)(y + ((size_t)b * T + t) * D + d0) = o;
+    }
+    if (ch == 0 && state_out != nullptr) {
+      // new_state[c][j] = ext[T + j], ext = [state(4), x(T)]
+      float ns[8][CONV_W];
+#pragma unroll
+      for (int j = 0; j < CONV_W; ++j) {
+        const int e = T + j;            // index into ext
+        if (e >= CONV_W) {
+          u32x4 v = *(const u32x4*)(xb + (size_t)(e - CONV_W) * D);
+          ns[0][j] = bflo(v.x); ns[1][j] = bfhi(v.x); ns[2][j] = bflo(v.y); ns[3][j] = bfhi(v.y);
+          ns[4][j] = bflo(v.z); ns[5][j] = bfhi(v.z); ns[6][j] = bflo(v.w); ns[7][j] = bfhi(v.w);
+        } else {
+#pragma unroll
+          for (int e2 = 0; e2 < CONV_W; ++e2)
+            if (e == e2) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) ns[c][j] = st[c][e2];
+            }
+        }
+      }
+      u32x4* op = (u32x4*)(state_out + ((size_t)b * D + d0) * CONV_W);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x4 o;
+        o.x = pack2bf(ns[2 * i][0], ns[2 * i][1]);
+        o.y = pack2bf(ns[2 * i][2], ns[2 * i][3]);
+        o.z = pack2bf(ns[2 * i + 1][0], ns[2 * i + 1][1]);
+        o.w = pack2bf(ns[2 * i + 1][2], ns[2 * i + 1][3]);
+        op[i] = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gated RMSNorm over rows of 256: half a wavefront (32 lanes x 8 bf16) per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate, const bf16_t* __restrict__ weight,
+    bf16_t* __restrict__ y, int rows, float eps) {
+  const int lane32 = threadIdx.x & 31;
+  const long long row0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
+  u32x4 wv = *(const u32x4*)(weight + lane32 * 8);
+  const float wf[8] = {bflo(wv.x), bfhi(wv.x), bflo(wv.y), bfhi(wv.y), bflo(wv.z), bfhi(wv.z), bflo(wv.w), bfhi(wv.w)};
+  for (long long r = row0; r < rows; r += stride) {
+    u32x4 xv = *(const u32x4*)(x + r * 256 + lane32 * 8);
+    u32x4 gv = *(const u32x4*)(gate + r * 256 + lane32 * 8);
+    float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+    float gf[8] = {bflo(gv.x), bfhi(gv.x), bflo(gv.y), bfhi(gv.y), bflo(gv.z), bfhi(gv.z), bflo(gv.w), bfhi(gv.w)};
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss = fmaf(xf[i], xf[i], ss);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
+    float o8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o8[i] = xf[i] * rstd * wf[i] * gf[i] * sigmoidf_(gf[i]);
+    u32x4 ov;
+    ov.x = pack2bf(o8[0], o8[1]); ov.y = pack2bf(o8[2], o8[3]);
+    ov.z = pack2bf(o8[4], o8[5]); ov.w = pack2bf(o8[6], o8[7]);
+    *(u32x4*)(y + r * 256 + lane32 * 8) = ov;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate math: beta = sigmoid(b) -> bf16 ; g = -exp(A_log[h]) * softplus(a + dt_bias[h]) -> fp32
+// softplus follows torch (threshold 20).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gdn_gate_kernel(
+    const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ A_log,
+    const float* __restrict__ dt_bias, float* __restrict__ g, bf16_t* __restrict__ beta, long long n, int H) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const float av = bf2f(a[i]) + dt_bias[h];
+    const float sp = av > 20.f ? av : log1pf(expf(av));
+    g[i] = -expf(A_log[h]) * sp;
+    beta[i] = f2bf(1.0f / (1.0f + expf(-bf2f(b[i]))));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-RoPE in place on time-major q [B,T,Hq,d], k [B,T,Hkv,d]; cos/sin bf16 [3,B,T,d].
+// One thread = one head x 8 channels of the first half and their partners in the second half.
+// bf16 rounding after each product and after the sum (== torch eager bf16 arithmetic, std:982-983).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mrope_kernel(
+    bf16_t* q, bf16_t* k, const bf16_t* __restrict__ cosp, const bf16_t* __restrict__ sinp,
+    int B, int T, int Hq, int Hkv, int d, int s0, int s1) {
+  const int half = d / 2;
+  const int CG = half / 8;                 // channel groups per head (first half)
+  const int HT = Hq + Hkv;
+  const long long total = (long long)B * T * HT * CG;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % CG);
+    const int h = (int)((idx / CG) % HT);
+    const long long bt = idx / ((long long)CG * HT);
+    const int c0 = cg * 8;
+    bf16_t* base = h < Hq ? q + (bt * Hq + h) * d : k + (bt * Hkv + (h - Hq)) * d;
+    u32x4 lo = *(const u32x4*)(base + c0);
+    u32x4 hi = *(const u32x4*)(base + c0 + half);
+    float x1[8] = {bflo(lo.x), bfhi(lo.x), bflo(lo.y), bfhi(lo.y), bflo(lo.z), bfhi(lo.z), bflo(lo.w), bfhi(lo.w)};
+    float x2[8] = {bflo(hi.x), bfhi(hi.x), bflo(hi.y), bfhi(hi.y), bflo(hi.z), bfhi(hi.z), bflo(hi.w), bfhi(hi.w)};
+    float o1[8], o2[8];
+    const long long plane = (long long)B * T * d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;                       // channel in the first half; partner c+half has the same section
+      const int sec = c < s0 ? 0 : (c < s0 + s1 ? 1 : 2);
+      const long long off = sec * plane + bt * d;
+      const float c1 = bf2f(cosp[off + c]), sn1 = bf2f(sinp[off + c]);
+      const float c2 = bf2f(cosp[off + c + half]), sn2 = bf2f(sinp[off + c + half]);
+      o1[i] = bf_round(bf_round(x1[i] * c1) + bf_round(-x2[i] * sn1));
+      o2[i] = bf_round(bf_round(x2[i] * c2) + bf_round(x1[i] * sn2));
+    }
+    u32x4 w1, w2;
+    w1.x = pack2bf(o1[0], o1[1]); w1.y = pack2bf(o1[2], o1[3]); w1.z = pack2bf(o1[4], o1[5]); w1.w = pack2bf(o1[6], o1[7]);
+    w2.x = pack2bf(o2[0], o2[1]); w2.y = pack2bf(o2[2], o2[3]); w2.z = pack2bf(o2[4], o2[5]); w2.w = pack2bf(o2[6], o2[7]);
+    *(u32x4*)(base + c0) = w1;
+    *(u32x4*)(base + c0 + half) = w2;
+  }
+}
+
+__global__ void counter_add_kernel(long long* c, long long delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
+}
+
+static inline int grid_for(long long work_items, int block = 256, int cap = 256 * 8) {
+  long long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace ivl
+
+using namespace ivl;
+
+extern "C" int ivl_abi_version(void) { return IVL_ABI_VERSION; }
+extern "C" const char* ivl_last_error(void) { return g_err; }
+
+extern "C" int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,
+                                  int B, int T, int D, int W, int apply_silu, void* stream) {
+  IVL_REQUIRE(x && weight && y, IVL_ERR_INVALID_ARG, "ivl_short_conv_fwd: NULL x/weight/y");
+  IVL_REQUIRE(B > 0 && T > 0 && D > 0, IVL_ERR_INVALID_ARG, "ivl_short_conv_fwd: B,T,D must be positive (got %d,%d,%d)", B, T, D);
+  IVL_REQUIRE(W == CONV_W, IVL_ERR_UNSUPPORTED, "ivl_short_conv_fwd: kernel size %d unsupported (built for 4)", W);
+  IVL_REQUIRE(D % 8 == 0, IVL_ERR_UNSUPPORTED, "ivl_short_conv_fwd: D=%d must be a multiple of 8", D);
+  const long long items = (long long)B * ((T + CONV_TCH - 1) / CONV_TCH) * (D / 8);
+  hipLaunchKernelGGL(short_conv_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)state_in, (bf16_t*)y, (bf16_t*)state_out,
+                     B, T, D, apply_silu);
+  return check_launch("ivl_short_conv_fwd");
+}
+
+extern "C" int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
+                                          int rows, int N, float eps, void* stream) {
+  IVL_REQUIRE(x && gate && weight && y, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_fwd: NULL pointer");
+  IVL_REQUIRE(rows > 0, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_fwd: rows=%d", rows);
+  IVL_REQUIRE(N == 256, IVL_ERR_UNSUPPORTED, "ivl_rmsnorm_swish_gate_fwd: N=%d unsupported (built for head_v_dim 256)", N);
+  hipLaunchKernelGGL(rmsnorm_gate_kernel, dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)weight, (bf16_t*)y, rows, eps);
+  return check_launch("ivl_rmsnorm_swish_gate_fwd");
+}
+
+extern "C" int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const float* dt_bias,
+                                float* g, void* beta, int rows, int H, void* stream) {
+  IVL_REQUIRE(a && b && A_log && dt_bias && g && beta, IVL_ERR_INVALID_ARG, "ivl_gdn_gate_fwd: NULL pointer");
+  IVL_REQUIRE(rows > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_gate_fwd: rows=%d H=%d", rows, H);
+  const long long n = (long long)rows * H;
+  hipLaunchKernelGGL(gdn_gate_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, A_log, dt_bias, g, (bf16_t*)beta, n, H);
+  return check_launch("ivl_gdn_gate_fwd");
+}
+
+extern "C" int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
+                             int B, int T, int Hq, int Hkv, int d, int s0, int s1, int s2, void* stream) {
+  IVL_REQUIRE(q && k && cos && sin, IVL_ERR_INVALID_ARG, "ivl_mrope_fwd: NULL pointer");
+  IVL_REQUIRE(B > 0 && T > 0 && Hq > 0 && Hkv > 0, IVL_ERR_INVALID_ARG, "ivl_mrope_fwd: bad sizes");
+  IVL_REQUIRE(d % 16 == 0 && s0 + s1 + s2 == d / 2, IVL_ERR_UNSUPPORTED,
+              "ivl_mrope_fwd: need d%%16==0 and s0+s1+s2==d/2 (d=%d, sections %d,%d,%d)", d, s0, s1, s2);
+  const long long items = (long long)B * T * (Hq + Hkv) * (d / 16);
+  hipLaunchKernelGGL(mrope_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)q, (bf16_t*)k, (const bf16_t*)cos, (const bf16_t*)sin, B, T, Hq, Hkv, d, s0, s1);
+  return check_launch("ivl_mrope_fwd");
+}
+
+extern "C" int ivl_counter_add(int64_t* counter, int64_t delta, void* stream) {
+  IVL_REQUIRE(counter, IVL_ERR_INVALID_ARG, "ivl_counter_add: NULL counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counter, (long long)delta);
+  return check_launch("ivl_counter_add");
+}

@@ -1,0 +1,419 @@
+// Sliding-window attention for gfx950: flash-style online softmax on MFMA 16x16x32 bf16, GQA,
+// head_dim 128, reading the ring-buffer KV cache in place (no torch.cat) plus the call's new K/V.
+//
+// Formulation (everything per query row stays inside one lane group; no P round trip through LDS):
+//   S^T = K Q^T      A = K tile rows (keys)      B = Q^T            -> lane owns ONE query row
+//   O^T = V^T P^T    A = V^T (LDS transpose read) B = P^T (in regs) -> same lane owns that row's O
+// A 64-key tile is staged once per workgroup (4 waves x 16 query rows) into LDS: K rows of 256 B with a
+// 16-byte-chunk XOR swizzle (conflict-free ds_read_b128 of MFMA A fragments), V rows padded to 288 B
+// (conflict-free ds_read_b64_tr_b16).  The key -> MFMA k-slot map of the PV product is permuted so the
+// probabilities produced by the first MFMA feed the second one without any cross-lane movement:
+//   slot 8g+e  <->  key 32*ks + 4g + e (e<4)  |  key 32*ks + 16 + 4g + (e-4) (e>=4).
+// Band (bit-exact contract): row with token index t sees call-local keys
+//   lo = max(0, n_prev + t - W + 1) .. hi = n_prev + t.
+// Long key ranges are optionally split across workgroups (flash-decoding); a combine kernel merges.
+#include "ivl_common.h"
+
+namespace ivl {
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SWA_D = 128;
+constexpr int SWA_QT = 64;           // query rows per workgroup
+constexpr int SWA_KT = 64;           // keys per tile
+constexpr int SWA_KSTRIDE = 256;     // bytes per K row in LDS (swizzled)
+constexpr int SWA_VSTRIDE = 288;     // bytes per V row in LDS (padded)
+constexpr int SWA_LDS_K = SWA_KT * SWA_KSTRIDE;
+constexpr int SWA_LDS_BYTES = SWA_LDS_K + SWA_KT * SWA_VSTRIDE;
+constexpr int SWA_MAX_SPLIT = 16;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct SwaParams {
+  const bf16_t* q; const bf16_t* k_new; const bf16_t* v_new; const bf16_t* k_cache; const bf16_t* v_cache;
+  bf16_t* o;
+  long long q_sb, q_st, q_sh, kn_sb, kn_st, kn_sh;
+  int B, T, T_new, Hq, Hkv, C, W, nsplit;
+  long long pos; const long long* pos_dev;
+  float scaling;
+  float* part_o; float* part_ml;
+};
+
+__device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
+  mfma_bf16x8 r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
+}
+
+template <bool PACK, bool TR>
+__global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SWA_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int G = p.Hq / p.Hkv;
+  const int b = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  const int hk = PACK ? (int)blockIdx.y : (int)blockIdx.y / G;
+
+  const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
+  const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
+  const int n_extra = p.T_new - p.T;
+  const int n_prev = n_ring + n_extra;
+  const int S = n_prev + p.T;
+  const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;     // ring slot of call-local key 0
+
+  // ---- rows of this workgroup / wave / lane ----------------------------------------------------
+  const int total_rows = PACK ? p.T * G : p.T;
+  const int tile_row0 = blockIdx.x * SWA_QT;
+  const int row = tile_row0 + wave * 16 + l15;
+  const bool row_ok = row < total_rows;
+  const int t_row = PACK ? row / G : row;
+  const int hq = PACK ? hk * G + row % G : (int)blockIdx.y;
+  const int hi = n_prev + t_row;
+  const int lo = p.W > 0 ? max(0, n_prev + t_row - p.W + 1) : 0;
+
+  // workgroup key-tile range
+  const int last_row = min(tile_row0 + SWA_QT, total_rows) - 1;
+  const int t_min = PACK ? tile_row0 / G : tile_row0;
+  const int t_max = PACK ? last_row / G : last_row;
+  const int lo_min = p.W > 0 ? max(0, n_prev + t_min - p.W + 1) : 0;
+  const int kt0 = lo_min / SWA_KT, kt1 = (n_prev + t_max) / SWA_KT + 1;
+  const int per = (kt1 - kt0 + p.nsplit - 1) / p.nsplit;
+  const int kt_begin = kt0 + split * per;
+  const int kt_end = min(kt1, kt_begin + per);
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane = query row, k-slots 8g..8g+7 of each 32-chunk ----
+  u32x4 qf[4];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)t_row * p.q_st + (long long)hq * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (row_ok) qf[ks] = *(const u32x4*)(qp + 32 * ks + 8 * g);
+      else qf[ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 oacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: thread -> rows (tid>>4) + 16 i, 16-byte chunk tid&15 ------------------------------
+  const int srow = tid >> 4, schunk = tid & 15;
+  u32x4 kreg[4], vreg[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 16 * i;
+      const int j = kt * SWA_KT + r;
+      if (j < S) {
+        const bf16_t *kp, *vp;
+        if (j < n_ring) {
+          int slot = s0 + j;
+          if (slot >= p.C) slot -= p.C;
+          const long long off = (((long long)b * p.Hkv + hk) * p.C + slot) * SWA_D + schunk * 8;
+          kp = p.k_cache + off;
+          vp = p.v_cache + off;
+        } else {
+          const long long off = (long long)b * p.kn_sb + (long long)(j - n_ring) * p.kn_st + (long long)hk * p.kn_sh + schunk * 8;
+          kp = p.k_new + off;
+          vp = p.v_new + off;
+        }
+        kreg[i] = *(const u32x4*)kp;
+        vreg[i] = *(const u32x4*)vp;
+      } else {
+        kreg[i] = u32x4{0u, 0u, 0u, 0u};
+        vreg[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 16 * i;
+      *(u32x4*)(smem + r * SWA_KSTRIDE + ((schunk ^ (r & 15)) << 4)) = kreg[i];
+      *(u32x4*)(smem + SWA_LDS_K + r * SWA_VSTRIDE + schunk * 16) = vreg[i];
+    }
+  };
+
+  if (kt_begin < kt_end) load_tile(kt_begin);
+  const float sc = p.scaling * LOG2E;
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt_end) load_tile(kt + 1);
+
+    // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps -------------------------------------------
+    f32x4 sacc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int kr = 16 * mt + l15;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 kf = *(const u32x4*)(smem + kr * SWA_KSTRIDE + (((4 * ks + g) ^ (kr & 15)) << 4));
+        sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(kf), as_mfma(qf[ks]), sacc[mt], 0, 0, 0);
+      }
+    }
+    // ---- band mask + online softmax (lane-local row) ------------------------------------------
+    const int jbase = kt * SWA_KT + 4 * g;
+    float rmax = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jbase + 16 * mt + r;
+        const bool vis = row_ok && j >= lo && j <= hi;
+        const float s = vis ? sacc[mt][r] * sc : -INFINITY;
+        sacc[mt][r] = s;
+        rmax = fmaxf(rmax, s);
+      }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    const float m_new = fmaxf(m_run, rmax);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);          // m_run = -inf -> 0
+    float rsum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = exp2f(sacc[mt][r] - m_use);
+        sacc[mt][r] = pv;
+        rsum += pv;
+      }
+    rsum += __shfl_xor(rsum, 16, 64);
+    rsum += __shfl_xor(rsum, 32, 64);
+    l_run = l_run * alpha + rsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oacc[i] *= alpha;
+
+    // ---- P^T fragments (B operand): slots 8g+e <-> keys 32ks2+4g+e | 32ks2+16+4g+(e-4) ---------
+    u32x4 pf[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      pf[ks2].x = pack2bf(sacc[2 * ks2][0], sacc[2 * ks2][1]);
+      pf[ks2].y = pack2bf(sacc[2 * ks2][2], sacc[2 * ks2][3]);
+      pf[ks2].z = pack2bf(sacc[2 * ks2 + 1][0], sacc[2 * ks2 + 1][1]);
+      pf[ks2].w = pack2bf(sacc[2 * ks2 + 1][2], sacc[2 * ks2 + 1][3]);
+    }
+    // ---- O^T += V^T P^T : 8 d sub-tiles x 2 key-steps ------------------------------------------
+    const unsigned char* vbase = smem + SWA_LDS_K;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2) {
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        u32x4 vf;
+        if (TR) {
+          // 16-lane group g reads the 4x16 block rows (32ks2 [+16] + 4g .. +3), cols 16mt2..+15;
+          // lane i supplies the address of row (i>>2), cols 4(i&3)..+3 and receives column i.
+          const int r0 = 32 * ks2 + 4 * g + (l15 >> 2);
+          const int cb = (16 * mt2 + 4 * (l15 & 3)) * 2;
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + r0 * SWA_VSTRIDE + cb));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + (r0 + 16) * SWA_VSTRIDE + cb));
+          u32x2 w0, w1;
+          __builtin_memcpy(&w0, &a0, 8);
+          __builtin_memcpy(&w1, &a1, 8);
+          vf = u32x4{w0.x, w0.y, w1.x, w1.y};
+        } else {
+          const int col = (16 * mt2 + l15) * 2;
+          const int r0 = 32 * ks2 + 4 * g;
+          unsigned short e[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            e[i] = *(const unsigned short*)(vbase + (r0 + i) * SWA_VSTRIDE + col);
+            e[4 + i] = *(const unsigned short*)(vbase + (r0 + 16 + i) * SWA_VSTRIDE + col);
+          }
+          vf = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                     (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        }
+        oacc[mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(vf), as_mfma(pf[ks2]), oacc[mt2], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns row `row`, d = 16 mt2 + 4g + r ---------------------------------------
+  if (!row_ok) return;
+  if (p.nsplit == 1) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* op = p.o + (((long long)b * p.T + t_row) * p.Hq + hq) * SWA_D + 4 * g;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2) {
+      u32x2 w;
+      w.x = pack2bf(oacc[mt2][0] * inv, oacc[mt2][1] * inv);
+      w.y = pack2bf(oacc[mt2][2] * inv, oacc[mt2][3] * inv);
+      *(u32x2*)(op + 16 * mt2) = w;
+    }
+  } else {
+    const long long prow = (((long long)b * p.nsplit + split) * p.T + t_row) * p.Hq + hq;
+    float* po = p.part_o + prow * SWA_D + 4 * g;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2) *(f32x4*)(po + 16 * mt2) = oacc[mt2];
+    if (g == 0) {
+      p.part_ml[prow * 2] = m_run;
+      p.part_ml[prow * 2 + 1] = l_run;
+    }
+  }
+}
+
+// merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane
+__global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                         bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit) {
+  const int lane = threadIdx.x & 63;
+  const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
+    const long long b = r / rows_per_b, rr = r % rows_per_b;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[((b * nsplit + s) * rows_per_b + rr) * 2]);
+    float l = 0.f, a0 = 0.f, a1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const long long pr = (b * nsplit + s) * rows_per_b + rr;
+      const float ms = part_ml[pr * 2];
+      const float w = ms == -INFINITY ? 0.f : exp2f(ms - m);
+      l += w * part_ml[pr * 2 + 1];
+      const float2 ov = *(const float2*)(part_o + pr * SWA_D + 2 * lane);
+      a0 = fmaf(w, ov.x, a0);
+      a1 = fmaf(w, ov.y, a1);
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    *(unsigned int*)(o + r * SWA_D + 2 * lane) = pack2bf(a0 * inv, a1 * inv);
+  }
+}
+
+// ring append: token t of the call -> slot (pos + t) % C ; only the last min(T, C) tokens are written
+__global__ __launch_bounds__(256) void swa_cache_append_kernel(
+    const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, long long kn_sb, long long kn_st, long long kn_sh,
+    bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int B, int T, int Hkv, int C,
+    long long pos_host, const long long* pos_dev) {
+  const long long pos = pos_dev ? *pos_dev : pos_host;
+  const int t_first = T > C ? T - C : 0;
+  const int nt = T - t_first;
+  const long long total = (long long)B * nt * Hkv * (SWA_D / 8);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % (SWA_D / 8));
+    const int hk = (int)((idx / (SWA_D / 8)) % Hkv);
+    const int tt = (int)((idx / ((long long)(SWA_D / 8) * Hkv)) % nt) + t_first;
+    const int b = (int)(idx / ((long long)(SWA_D / 8) * Hkv * nt));
+    const int slot = (int)((pos + tt) % C);
+    const long long src = (long long)b * kn_sb + (long long)tt * kn_st + (long long)hk * kn_sh + ch * 8;
+    const long long dst = (((long long)b * Hkv + hk) * C + slot) * SWA_D + ch * 8;
+    *(u32x4*)(k_cache + dst) = *(const u32x4*)(k_new + src);
+    *(u32x4*)(v_cache + dst) = *(const u32x4*)(v_new + src);
+  }
+}
+
+static int swa_base_nsplit(int B, int T, int Hq) {
+  const long long base = (long long)B * ((T + SWA_QT - 1) / SWA_QT) * Hq;
+  long long ns = (1024 + base - 1) / base;
+  if (ns < 1) ns = 1;
+  if (ns > SWA_MAX_SPLIT) ns = SWA_MAX_SPLIT;
+  return (int)ns;
+}
+
+static bool swa_use_tr() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IVL_SWA_NO_TR");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v == 1;
+}
+
+}  // namespace ivl
+
+using namespace ivl;
+
+extern "C" size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d) {
+  if (B <= 0 || T <= 0 || Hq <= 0 || d != SWA_D) return 0;
+  int ns = swa_base_nsplit(B, T, Hq);
+  if (T <= SWA_QT) ns = SWA_MAX_SPLIT;      // packed decode rows may use the maximum split
+  if (ns == 1) return 256;
+  return (size_t)B * ns * T * Hq * (SWA_D + 2) * sizeof(float) + 256;
+}
+
+extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
+  IVL_REQUIRE(a != nullptr, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: NULL args");
+  IVL_REQUIRE(a->q && a->k_new && a->v_new && a->o, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: NULL q/k_new/v_new/o");
+  IVL_REQUIRE(a->B > 0 && a->T > 0 && a->T_new >= a->T && a->Hq > 0 && a->Hkv > 0, IVL_ERR_INVALID_ARG,
+              "ivl_swa_fwd: bad sizes B=%d T=%d T_new=%d Hq=%d Hkv=%d", a->B, a->T, a->T_new, a->Hq, a->Hkv);
+  IVL_REQUIRE(a->d == SWA_D, IVL_ERR_UNSUPPORTED, "ivl_swa_fwd: head_dim %d unsupported (built for 128)", a->d);
+  IVL_REQUIRE(a->Hq % a->Hkv == 0, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: Hq=%d not a multiple of Hkv=%d", a->Hq, a->Hkv);
+  IVL_REQUIRE(a->cache_capacity >= 0 && (a->cache_capacity == 0 || (a->k_cache && a->v_cache)), IVL_ERR_INVALID_ARG,
+              "ivl_swa_fwd: cache_capacity=%d needs k_cache/v_cache", a->cache_capacity);
+  IVL_REQUIRE(a->pos_dev != nullptr || a->pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: negative pos");
+  const int G = a->Hq / a->Hkv;
+  const bool pack = (long long)a->T * G <= SWA_QT && G <= 16;
+  // worst-case number of key tiles a workgroup walks (n_prev unknown under graph replay -> capacity)
+  const long long max_prev = (long long)a->cache_capacity + (a->T_new - a->T);
+  long long span = a->window > 0 ? (long long)a->window + SWA_QT : max_prev + a->T;
+  if (span > max_prev + a->T) span = max_prev + a->T;
+  const int max_tiles = (int)(span / SWA_KT) + 2;
+  int nsplit = 1;
+  if (pack) {
+    nsplit = max_tiles / 2;
+  } else {
+    nsplit = swa_base_nsplit(a->B, a->T, a->Hq);
+    if (nsplit > max_tiles / 4) nsplit = max_tiles / 4;
+  }
+  if (nsplit > SWA_MAX_SPLIT) nsplit = SWA_MAX_SPLIT;
+  if (nsplit < 1) nsplit = 1;
+
+  SwaParams p;
+  p.q = (const bf16_t*)a->q; p.k_new = (const bf16_t*)a->k_new; p.v_new = (const bf16_t*)a->v_new;
+  p.k_cache = (const bf16_t*)a->k_cache; p.v_cache = (const bf16_t*)a->v_cache; p.o = (bf16_t*)a->o;
+  p.q_sb = a->q_sb; p.q_st = a->q_st; p.q_sh = a->q_sh; p.kn_sb = a->kn_sb; p.kn_st = a->kn_st; p.kn_sh = a->kn_sh;
+  p.B = a->B; p.T = a->T; p.T_new = a->T_new; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity; p.W = a->window;
+  p.nsplit = nsplit; p.pos = a->pos; p.pos_dev = (const long long*)a->pos_dev; p.scaling = a->scaling;
+  p.part_o = nullptr; p.part_ml = nullptr;
+  if (nsplit > 1) {
+    const size_t n_o = (size_t)a->B * nsplit * a->T * a->Hq * SWA_D;
+    const size_t need = (n_o + (size_t)a->B * nsplit * a->T * a->Hq * 2) * sizeof(float);
+    IVL_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= need, IVL_ERR_WORKSPACE,
+                "ivl_swa_fwd: workspace %zu bytes < required %zu (nsplit=%d)", a->workspace_bytes, need, nsplit);
+    p.part_o = (float*)a->workspace;
+    p.part_ml = p.part_o + n_o;
+  }
+  const int rows = pack ? a->T * G : a->T;
+  dim3 grid((rows + SWA_QT - 1) / SWA_QT, pack ? a->Hkv : a->Hq, a->B * nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  const bool tr = swa_use_tr();
+  if (pack) {
+    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((swa_fwd_kernel<true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((swa_fwd_kernel<false, false>), grid, dim3(256), 0, st, p);
+  }
+  int rc = check_launch("ivl_swa_fwd");
+  if (rc != IVL_OK) return rc;
+  if (nsplit > 1) {
+    const long long nrows = (long long)a->B * a->T * a->Hq;
+    long long gb = (nrows * 64 + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(swa_combine_kernel, dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    rc = check_launch("ivl_swa_fwd(combine)");
+  }
+  return rc;
+}
+
+extern "C" int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
+                                    void* k_cache, void* v_cache, int B, int T, int Hkv, int d, int cache_capacity,
+                                    int64_t pos, const int64_t* pos_dev, void* stream) {
+  IVL_REQUIRE(k_new && v_new && k_cache && v_cache, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: NULL pointer");
+  IVL_REQUIRE(B > 0 && T > 0 && Hkv > 0 && cache_capacity > 0, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: bad sizes");
+  IVL_REQUIRE(d == SWA_D, IVL_ERR_UNSUPPORTED, "ivl_swa_cache_append: head_dim %d unsupported", d);
+  IVL_REQUIRE(pos_dev != nullptr || pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: negative pos");
+  const int nt = T > cache_capacity ? cache_capacity : T;
+  long long items = (long long)B * nt * Hkv * (SWA_D / 8);
+  long long gb = (items + 255) / 256;
+  if (gb > 2048) gb = 2048;
+  hipLaunchKernelGGL(swa_cache_append_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)k_new, (const bf16_t*)v_new, (long long)kn_sb, (long long)kn_st, (long long)kn_sh,
+                     (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, Hkv, cache_capacity, (long long)pos, (const long long*)pos_dev);
+  return check_launch("ivl_swa_cache_append");
+}

@@ -1,0 +1,244 @@
+"""Harness around the hot path: the build's own counterpart of the
+reference's decoder layer / text-model loop (std:1350-1429, 1549-1575), `allocate_inference_cache`
+(std:2316-2322) and the CUDA-graph streaming demo (inference_examples/demo_streaming_inference.py:
+262-269 static buffers, 473-489 capture/replay, 399-422 greedy loop, 111-160 cache clone).
+
+Everything that is not the Gated DeltaNet / SWA mixer (RMSNorm, SwiGLU MLP, embeddings, lm_head) is
+stock PyTorch-ROCm (rocBLAS/hipBLASLt GEMMs): callers of the path, kept as-is.
+
+`std:` = infinitevl/infinitevl_standard/modeling_infinitevl.py of the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .cache import StaticCachePrealloc
+from .modules import GatedDeltaNet, InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
+
+
+@dataclass
+class InfiniteVLTextConfig:
+    """The fields of the reference's InfiniteVLTextConfig that the hot path reads
+    (configuration_infinitevl.py:208-284); defaults = the shipped InfiniteVL-3B config.json."""
+    vocab_size: int = 151936
+    hidden_size: int = 2048
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 36
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 2
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    norm_eps: float = 1e-5
+    rope_theta: float = 1e6
+    rope_scaling: Dict = field(default_factory=lambda: {"type": "default", "rope_type": "default",
+                                                         "mrope_section": [16, 24, 24]})
+    sliding_window: int = 8192
+    use_sliding_window: bool = True
+    layer_types: Optional[List[str]] = None
+    attention_dropout: float = 0.0
+    max_position_embeddings: int = 128000
+    tie_word_embeddings: bool = True
+    expand_v: float = 2
+    mode: str = "chunk"
+    use_gate: bool = True
+    use_short_conv: bool = True
+    conv_size: int = 4
+    conv_bias: bool = False
+    num_linear_heads: int = 16
+    num_linear_key_value_heads: int = 16
+    linear_head_dim: int = 128
+
+    def __post_init__(self):
+        if self.layer_types is None:            # configuration_infinitevl.py:278-284: every 4th layer is SWA
+            self.layer_types = ["sliding_attention" if i % 4 == 0 else "linear_attention"
+                                for i in range(self.num_hidden_layers)]
+
+
+class InfiniteVLRMSNorm(nn.Module):
+    """Qwen2RMSNorm (std:50): fp32 statistics, cast back, times weight."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        dt = x.dtype
+        xf = x.to(torch.float32)
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * xf.to(dt)
+
+
+class InfiniteVLTextMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class InfiniteVLDecoderLayer(nn.Module):
+    """std:1350-1429: RMSNorm -> mixer -> +res -> RMSNorm -> SwiGLU -> +res."""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.layer_type = config.layer_types[layer_idx]
+        if self.layer_type == "linear_attention":
+            self.self_attn = GatedDeltaNet(config, layer_idx)
+        else:
+            self.self_attn = InfiniteVLSelfAttention(config, layer_idx)
+        self.mlp = InfiniteVLTextMLP(config)
+        self.input_layernorm = InfiniteVLRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = InfiniteVLRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None,
+                output_attentions=False, use_cache=False, cache_position=None, position_embeddings=None, **kwargs):
+        residual = hidden_states
+        h = self.input_layernorm(hidden_states)
+        h, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
+                              past_key_values=past_key_values, output_attentions=output_attentions,
+                              use_cache=use_cache, cache_position=cache_position,
+                              position_embeddings=position_embeddings, **kwargs)
+        hidden_states = residual + h
+        residual = hidden_states
+        h = self.mlp(self.post_attention_layernorm(hidden_states))
+        return (residual + h,)
+
+
+class InfiniteVLTextStack(nn.Module):
+    """Embedding + N decoder layers + final norm + tied lm_head: the text side of the model as the
+    streaming demo drives it (inputs_embeds already contain the ViT features)."""
+
+    def __init__(self, config: InfiniteVLTextConfig):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([InfiniteVLDecoderLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.norm = InfiniteVLRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.rotary_emb = InfiniteVLRotaryEmbedding(config)
+
+    @torch.no_grad()
+    def init_weights_(self, seed: int = 0, std: float = 0.02) -> "InfiniteVLTextStack":
+        """Random init in the spirit of the reference's initializer_range=0.02 (no checkpoint offline)."""
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for name, p_ in self.named_parameters():
+            if name.endswith("A_log") or name.endswith("dt_bias"):
+                continue
+            if "layernorm" in name or name.endswith("norm.weight"):
+                p_.fill_(1.0)
+            elif "conv1d" in name:
+                p_.copy_(torch.randn(p_.shape, generator=gen) * 0.3)
+            elif name.endswith(".bias"):
+                p_.copy_(torch.randn(p_.shape, generator=gen) * std)
+            else:
+                p_.copy_(torch.randn(p_.shape, generator=gen) * std)
+        return self
+
+    def allocate_inference_cache(self, batch_size: int = 1, dtype: Optional[torch.dtype] = None,
+                                 zero_init: bool = False) -> StaticCachePrealloc:
+        p_ = next(self.parameters())
+        return StaticCachePrealloc(config=self.config, batch_size=batch_size, device=p_.device,
+                                   dtype=dtype or p_.dtype, zero_init=zero_init)
+
+    def forward(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None, past_key_values: Optional[StaticCachePrealloc] = None,
+                cache_position: Optional[torch.Tensor] = None, logits_to_keep: int = 1
+                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        B, T, _ = inputs_embeds.shape
+        if position_ids is None:
+            start = past_key_values.get_seq_length() if past_key_values is not None else 0
+            position_ids = torch.arange(start, start + T, device=inputs_embeds.device)[None, None, :].expand(3, B, T)
+        position_embeddings = self.rotary_emb(inputs_embeds, position_ids)           # std:1549
+        h = inputs_embeds
+        for layer in self.layers:                                                    # std:1555-1571
+            h = layer(h, position_ids=position_ids, past_key_values=past_key_values,
+                      use_cache=past_key_values is not None, cache_position=cache_position,
+                      position_embeddings=position_embeddings)[0]
+        h = self.norm(h)
+        logits = None
+        if logits_to_keep:
+            logits = F.linear(h[:, -logits_to_keep:, :], self.embed_tokens.weight)  # tied lm_head (std:2091-2092)
+        return h, logits
+
+
+def clone_inference_cache(cache: StaticCachePrealloc) -> StaticCachePrealloc:
+    """demo:111-160."""
+    return cache.clone()
+
+
+class GraphedStep:
+    """One hipGraph-captured forward of fixed length T over static input buffers
+    (demo:262-269, 473-489).  The cache carries device-resident counters, so the same graph is valid
+    for every step; positions advance inside the graph."""
+
+    def __init__(self, model: InfiniteVLTextStack, cache: StaticCachePrealloc, batch_size: int, T: int,
+                 logits_to_keep: int = 1, warmup: int = 2):
+        p_ = next(model.parameters())
+        self.model, self.cache, self.T, self.B = model, cache, T, batch_size
+        self.inputs_embeds = torch.zeros(batch_size, T, model.config.hidden_size, dtype=p_.dtype, device=p_.device)
+        start = cache.get_seq_length()
+        self.position_ids = (torch.arange(start, start + T, device=p_.device, dtype=torch.int64)[None, None, :]
+                             .expand(3, batch_size, T).contiguous())
+        self.logits_to_keep = logits_to_keep
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.hidden = self.logits = None
+        self._warmup = warmup
+
+    def _run(self):
+        h, lg = self.model(inputs_embeds=self.inputs_embeds, position_ids=self.position_ids,
+                           past_key_values=self.cache, logits_to_keep=self.logits_to_keep)
+        self.position_ids.add_(self.T)
+        return h, lg
+
+    def capture(self) -> None:
+        """Warm up on a side stream with a throw-away clone of the cache state (demo:285-315), then
+        capture.  The live cache is restored afterwards, so capture has no side effects on it."""
+        saved = self.cache.clone()
+        saved_pos = self.position_ids.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(self._warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.hidden, self.logits = self._run()
+        self.cache.copy_from(saved)
+        self.position_ids.copy_(saved_pos)
+
+    def step(self, inputs_embeds: Optional[torch.Tensor] = None):
+        if self.graph is None:
+            self.capture()
+        if inputs_embeds is not None:
+            self.inputs_embeds.copy_(inputs_embeds)
+        self.graph.replay()
+        self.cache.advance(self.T)
+        return self.hidden, self.logits
+
+
+@torch.no_grad()
+def greedy_decode(model: InfiniteVLTextStack, cache: StaticCachePrealloc, first_token: torch.Tensor, steps: int,
+                  start_pos: Optional[int] = None) -> torch.Tensor:
+    """Eager greedy loop of single-token forwards (demo:399-422)."""
+    B = first_token.shape[0]
+    pos = cache.get_seq_length() if start_pos is None else start_pos
+    tok = first_token.view(B, 1)
+    out = []
+    for _ in range(steps):
+        pid = torch.full((3, B, 1), pos, device=tok.device, dtype=torch.int64)
+        _, logits = model(input_ids=tok, position_ids=pid, past_key_values=cache)
+        tok = logits[:, -1].argmax(-1, keepdim=True)
+        out.append(tok)
+        pos += 1
+    return torch.cat(out, dim=1)

@@ -1,0 +1,219 @@
+"""Drop-in mixer modules: same class names, constructor arguments, parameter names/shapes,
+forward signatures and return values as the reference's `GatedDeltaNet` (std:1116-1347) and
+`InfiniteVLSelfAttention` (std:987-1113), so they slot into `InfiniteVLDecoderLayer`
+(std:1361-1364) and load the reference checkpoint unchanged.  The arithmetic between the
+projections runs in the gfx950 kernels (infinitevl_amd.ops); the projections themselves are stock
+rocBLAS/hipBLASLt GEMMs through torch (out of scope).
+
+`std:` = infinitevl/infinitevl_standard/modeling_infinitevl.py of the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cache import StaticLinearLayerPrealloc, StaticSlidingWindowLayerPrealloc
+
+
+class InfiniteVLRotaryEmbedding(nn.Module):
+    """3-D (t,h,w) rotary tables cos/sin [3,B,T,head_dim] in the activation dtype (std:896-930,
+    'default' rope init)."""
+
+    def __init__(self, config, device=None):
+        super().__init__()
+        self.config = config
+        head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        theta = float(getattr(config, "rope_theta", 1e6))
+        inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+        self.register_buffer("inv_freq", inv_freq.to(device) if device is not None else inv_freq, persistent=False)
+        self.attention_scaling = 1.0
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, position_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        inv = self.inv_freq[None, None, :, None].float().expand(3, position_ids.shape[1], -1, 1)
+        pos = position_ids[:, :, None, :].float()
+        freqs = (inv @ pos).transpose(2, 3)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return (emb.cos() * self.attention_scaling).to(x.dtype), (emb.sin() * self.attention_scaling).to(x.dtype)
+
+
+class InfiniteVLSelfAttention(nn.Module):
+    """Sliding-window GQA attention mixer (std:987-1113)."""
+
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.layer_idx = layer_idx
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.is_causal = True
+        self.attention_dropout = getattr(config, "attention_dropout", 0.0)
+        self.rope_scaling = config.rope_scaling
+        self.scaling = self.head_dim ** -0.5
+        if (self.head_dim * self.num_heads) != self.hidden_size:
+            raise ValueError(
+                f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                f" and `num_heads`: {self.num_heads}).")
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=True)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.sliding_window = (config.sliding_window
+                               if config.layer_types[self.layer_idx] == "sliding_attention" else None)
+        self.rotary_emb = InfiniteVLRotaryEmbedding(config=config)
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.LongTensor] = None, past_key_values=None,
+                output_attentions: bool = False, use_cache: bool = False,
+                cache_position: Optional[torch.LongTensor] = None,
+                position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, **kwargs):
+        bsz, q_len, _ = hidden_states.size()
+        # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        cos, sin = position_embeddings
+        ops.apply_mrope_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])       # std:1057-1064
+
+        layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
+        if isinstance(layer, StaticSlidingWindowLayerPrealloc):
+            attn = layer.attend(q, k, v, self.scaling, self.sliding_window)               # std:1067-1108 fused
+        elif layer is None:
+            attn = ops.swa_forward(q, k, v, window=self.sliding_window, scaling=self.scaling)
+        else:  # foreign cache object: go through the reference protocol (cat of cached + new)
+            fk, fv = past_key_values.update(layer_idx=self.layer_idx, key_states=k.transpose(1, 2),
+                                            value_states=v.transpose(1, 2), conv_state=None, recurrent_state=None,
+                                            cache_kwargs={"sin": sin, "cos": cos, "cache_position": cache_position})
+            attn, _ = ops.swa_attention_interface(self, q.transpose(1, 2), fk, fv, None, scaling=self.scaling,
+                                                  sliding_window=self.sliding_window)
+        attn = attn.reshape(bsz, q_len, -1)
+        return self.o_proj(attn), None
+
+
+class GatedDeltaNet(nn.Module):
+    """Gated DeltaNet mixer (std:1116-1347): q/k/v short convs, gates, delta-rule kernel, gated norm."""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.mode = config.mode
+        self.hidden_size = config.hidden_size
+        self.expand_v = config.expand_v
+        self.norm_eps = config.norm_eps
+        self.use_gate = config.use_gate
+        self.use_short_conv = config.use_short_conv
+        self.conv_size = config.conv_size
+        self.conv_bias = config.conv_bias
+        self.num_heads = config.num_linear_heads
+        self.num_key_value_heads = config.num_linear_key_value_heads
+        self.head_dim = getattr(config, "linear_head_dim", config.hidden_size // config.num_attention_heads)
+        self.key_dim = int(self.num_key_value_heads * self.head_dim)
+        self.value_dim = int(self.key_dim * self.expand_v)
+        self.head_k_dim = self.head_dim
+        self.head_v_dim = int(self.head_dim * self.expand_v)
+        self.layer_idx = layer_idx
+        if not math.isclose(self.key_dim * self.expand_v, self.value_dim, rel_tol=1e-5):
+            raise ValueError(f"expand_v={self.expand_v} does not produce an integer value when multiplied by "
+                             f"key_dim={self.key_dim}.")
+        if not math.isclose(self.head_dim * self.expand_v, self.head_v_dim, rel_tol=1e-5):
+            raise ValueError(f"expand_v={self.expand_v} does not produce an integer value when multiplied by "
+                             f"head_dim={self.head_dim}.")
+        assert self.mode in ["chunk", "fused_recurrent"], f"Not suppoerted mode `{self.mode}`."
+        if not self.use_short_conv:
+            raise UserWarning("ShortConvolution is crucial to the performance. Do not turn it off.")
+        if not self.use_gate:
+            raise NotImplementedError("InfiniteVL ships use_gate=True (configuration_infinitevl.py)")
+
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(self.hidden_size, self.key_dim, bias=False)
+        self.v_proj = nn.Linear(self.hidden_size, self.value_dim, bias=False)
+        self.a_proj = nn.Linear(self.hidden_size, self.num_heads, bias=False)
+        self.b_proj = nn.Linear(self.hidden_size, self.num_heads, bias=False)
+        A = torch.empty(self.num_heads, dtype=torch.float32).uniform_(0, 16)
+        self.A_log = nn.Parameter(torch.log(A))
+        self.A_log._no_weight_decay = True
+        dt_min, dt_max, dt_init_floor = 0.001, 0.1, 1e-4
+        dt = torch.exp(torch.rand(self.num_heads) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = torch.clamp(dt, min=dt_init_floor)
+        self.dt_bias = nn.Parameter(dt + torch.log(-torch.expm1(-dt)))
+        self.dt_bias._no_weight_decay = True
+        self.q_conv1d = ops.ShortConvolution(self.num_heads * self.head_dim, self.conv_size, activation="silu")
+        self.k_conv1d = ops.ShortConvolution(self.key_dim, self.conv_size, activation="silu")
+        self.v_conv1d = ops.ShortConvolution(self.value_dim, self.conv_size, activation="silu")
+        self.g_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_v_dim, bias=False)
+        self.o_norm = ops.FusedRMSNormGated(self.head_v_dim, eps=self.norm_eps)
+        self.o_proj = nn.Linear(self.num_heads * self.head_v_dim, self.hidden_size, bias=False)
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                past_key_values=None, cache_position: Optional[torch.LongTensor] = None, **kwargs):
+        # the reference nulls the mask (std:1223): padded batches are not supported by the path
+        batch_size, q_len, _ = hidden_states.shape
+        mode = "fused_recurrent" if q_len <= 64 else self.mode                        # std:1230
+        if kwargs.get("cu_seqlens", None) is not None:
+            raise NotImplementedError("variable-length inputs are not used by InfiniteVL (std:1223)")
+
+        layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
+        use_cache = past_key_values is not None
+        native = isinstance(layer, StaticLinearLayerPrealloc)
+        prev_conv, recurrent_state = (None, None, None), None
+        if use_cache:                                                                  # std:1241-1251
+            prev_conv, recurrent_state = past_key_values.update(
+                layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=None, recurrent_state=None,
+                cache_kwargs={"op": "get", "cache_position": cache_position})
+        # With our own cache class the kernels write conv / recurrent state straight into the pre-allocated
+        # tensors (in the cache dtype, i.e. the reference's fp32 -> cache-dtype rounding of std:335).
+        q_lin, k_lin, v_lin = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+        if native:
+            q, sq = _conv_into(self.q_conv1d, q_lin, prev_conv[0], layer.conv_state_q)
+            k, sk = _conv_into(self.k_conv1d, k_lin, prev_conv[1], layer.conv_state_k)
+            v, sv = _conv_into(self.v_conv1d, v_lin, prev_conv[2], layer.conv_state_v)
+        else:
+            q, sq = self.q_conv1d(q_lin, cache=prev_conv[0], output_final_state=use_cache)
+            k, sk = self.k_conv1d(k_lin, cache=prev_conv[1], output_final_state=use_cache)
+            v, sv = self.v_conv1d(v_lin, cache=prev_conv[2], output_final_state=use_cache)
+        q = q.view(batch_size, q_len, self.num_heads, self.head_dim)
+        k = k.view(batch_size, q_len, self.num_key_value_heads, self.head_k_dim)
+        v = v.view(batch_size, q_len, self.num_key_value_heads, self.head_v_dim)
+
+        g, beta = ops.gdn_gate(self.a_proj(hidden_states), self.b_proj(hidden_states), self.A_log, self.dt_bias)
+
+        fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+        o, next_state = fn(q=q, k=k, v=v, g=g, beta=beta, initial_state=recurrent_state,
+                           output_final_state=use_cache and not native, use_qk_l2norm_in_kernel=True,
+                           final_state_out=layer.recurrent_state if native else None)
+
+        if use_cache:                                                                  # std:1325-1333
+            past_key_values.update(
+                layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=(sq, sk, sv),
+                recurrent_state=next_state,
+                cache_kwargs={"op": "set", "delta_len": q_len, "cache_position": cache_position})
+
+        g_gate = self.g_proj(hidden_states).view(batch_size, q_len, self.num_heads, self.head_v_dim)
+        o = self.o_norm(o, g_gate)                                                     # std:1336-1338
+        o = self.o_proj(o.reshape(batch_size, q_len, -1))
+        return o, None
+
+
+def _conv_into(mod: "ops.ShortConvolution", x: torch.Tensor, prev: Optional[torch.Tensor], dst: torch.Tensor):
+    """Run the short conv reading history from `prev` (None = zero history, the reference's first call,
+    std:298-300) and writing the new state into the pre-allocated cache tensor `dst` (may alias prev)."""
+    from . import _lib
+    from .ops import _p, _stream
+    if dst.dtype != torch.bfloat16:
+        # non-bf16 cache: run on a bf16 copy of the history; cache.update(op="set") copies the result back
+        tmp = prev.to(torch.bfloat16) if prev is not None else None
+        return mod(x, cache=tmp, output_final_state=True)
+    B, T, D = x.shape
+    W = mod.kernel_size[0]
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    w = mod.weight if mod.weight.dtype == torch.bfloat16 else mod.weight.to(torch.bfloat16)
+    _lib.check(_lib.load().ivl_short_conv_fwd(_p(x), _p(w.contiguous()), _p(prev), _p(y), _p(dst), B, T, D, W,
+                                              int(mod.activation is not None), _stream(x)))
+    return y, dst

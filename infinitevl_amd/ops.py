@@ -1,0 +1,343 @@
+"""Operator-level host API: the same names, argument meaning and error behaviour as the
+third-party operators the reference calls (SURVEY.md section 8b "Operator-level contract"), backed by
+the gfx950 kernels of libivl_hip.so.  PyTorch is used for device memory and streams only.
+
+    chunk_gated_delta_rule / fused_recurrent_gated_delta_rule   <- fla.ops.gated_delta_rule  (std:1297-1320)
+    ShortConvolution, FusedRMSNormGated                         <- fla.modules               (std:1187-1210)
+    swa_attention_interface                                     <- ALL_ATTENTION_FUNCTIONS["flash_attention_2"] (std:1097-1108)
+    gdn_gate, apply_mrope_inplace                               <- torch glue at std:1293-1294 / std:1057-1064
+
+`std:` = infinitevl/infinitevl_standard/modeling_infinitevl.py of the reference.
+There is no CPU path: tensors must live on a ROCm device and the shared library must be built.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import IVL_BF16, IVL_F32, SwaArgs
+
+_DT_CODE = {torch.bfloat16: IVL_BF16, torch.float32: IVL_F32}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "infinitevl_amd ops run only on an MI355X (ROCm) device; got a CPU tensor. "
+                "There is deliberately no CPU fallback in the product path.")
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace: one growable scratch buffer per device, reused by every call on the current stream
+# ---------------------------------------------------------------------------------------------
+_WORKSPACES: Dict[Tuple[int, str], torch.Tensor] = {}
+
+
+def get_workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch.Tensor:
+    """Caller-owned scratch handed to the C ABI (the library never allocates).  Kernels that use it
+    are ordered by the stream, so one buffer per (device, tag) suffices; it only ever grows.  Growth
+    while a stream is being captured into a hipGraph is refused -- run one warm-up step first."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("workspace would have to grow during hipGraph capture; run a warm-up step first")
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+# ---------------------------------------------------------------------------------------------
+# Gated DeltaNet
+# ---------------------------------------------------------------------------------------------
+def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out):
+    _need_gpu(q, k, v, g, beta, initial_state)
+    assert q.dtype == k.dtype == v.dtype, "q, k, v must share a dtype"
+    assert len(beta.shape) == 3, "beta must be of shape [B, T, H]"                       # chunk.py:353
+    if q.dtype != torch.bfloat16:
+        raise ValueError(f"infinitevl_amd GDN kernels are built for bf16 activations, got {q.dtype}")
+    if cu_seqlens is not None:
+        if q.shape[0] != 1:                                                               # chunk.py:355-360
+            raise ValueError(
+                f"The batch size is expected to be 1 rather than {q.shape[0]} when using `cu_seqlens`."
+                f"Please flatten variable-length inputs before processing.")
+        raise NotImplementedError("variable-length (cu_seqlens) inputs are not used by InfiniteVL (std:1223)")
+    B, T, H, K = k.shape
+    V = v.shape[-1]
+    if scale is None:
+        scale = K ** -0.5                                                                 # chunk.py:373-374
+    else:
+        assert scale > 0, "Scale must be positive."
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    g = g.contiguous()
+    if g.dtype != torch.float32:
+        g = g.float()
+    beta = beta.contiguous()
+    if beta.dtype != torch.bfloat16:
+        beta = beta.to(torch.bfloat16)
+    if initial_state is not None:
+        if initial_state.dtype not in _DT_CODE:
+            initial_state = initial_state.float()
+        initial_state = initial_state.contiguous()
+        if tuple(initial_state.shape) != (B, H, K, V):
+            raise ValueError(f"initial_state shape {tuple(initial_state.shape)} != {(B, H, K, V)}")
+    ht = None
+    if final_state_out is not None:
+        if tuple(final_state_out.shape) != (B, H, K, V) or final_state_out.dtype not in _DT_CODE \
+                or not final_state_out.is_contiguous():
+            raise ValueError("final_state_out must be a contiguous [B,H,K,V] fp32/bf16 tensor")
+        ht = final_state_out
+    elif output_final_state:
+        ht = torch.empty(B, H, K, V, dtype=torch.float32, device=q.device)               # chunk_delta_h.py:291
+    o = torch.empty(B, T, H, V, dtype=q.dtype, device=q.device)
+    return q, k, v, g, beta, float(scale), initial_state, ht, o, (B, T, H, K, V)
+
+
+def fused_recurrent_gated_delta_rule(
+    q, k, v, g, beta, scale=None, initial_state=None, output_final_state=False, cu_seqlens=None,
+    use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
+):
+    """Token-recurrent gated delta rule (fla:ops/gated_delta_rule/fused_recurrent.py:218-335).
+
+    q,k [B,T,H,K] bf16, v [B,T,H,V] bf16, g [B,T,H] fp32 log-decay, beta [B,T,H]; returns
+    (o [B,T,H,V] bf16, final_state [B,H,K,V] fp32 or None).  `final_state_out` (extension) makes the
+    kernel write the state straight into a caller tensor (fp32 or bf16, may alias initial_state)."""
+    q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
+        q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
+    lib = _lib.load()
+    _lib.check(lib.ivl_gdn_recurrent_fwd(
+        _p(q), _p(k), _p(v), _p(g), _p(beta), _p(o),
+        _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
+        _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
+        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _stream(q)))
+    return o, ht
+
+
+def chunk_gated_delta_rule(
+    q, k, v, g, beta, scale=None, initial_state=None, output_final_state=False, cu_seqlens=None,
+    use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
+):
+    """Chunkwise gated delta rule, chunk 64 (fla:ops/gated_delta_rule/chunk.py:272-392).  Same I/O
+    as fused_recurrent_gated_delta_rule; any T >= 1."""
+    q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
+        q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
+    lib = _lib.load()
+    nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, T, H, K, V)
+    if nbytes == 0:
+        raise ValueError(f"chunk_gated_delta_rule: unsupported head shape K={K}, V={V} (built for 128/256)")
+    ws = get_workspace(nbytes, q.device, "gdn")
+    _lib.check(lib.ivl_gdn_chunk_fwd(
+        _p(q), _p(k), _p(v), _p(g), _p(beta), _p(o),
+        _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
+        _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
+        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _p(ws), ws.numel(), _stream(q)))
+    return o, ht
+
+
+def gdn_gate(a: torch.Tensor, b: torch.Tensor, A_log: torch.Tensor, dt_bias: torch.Tensor):
+    """g = -exp(A_log) * softplus(a + dt_bias) (fp32), beta = sigmoid(b) (bf16); std:1293-1294.
+    a, b are the a_proj / b_proj outputs [..., H] in bf16."""
+    _need_gpu(a, b)
+    H = a.shape[-1]
+    a, b = a.contiguous(), b.contiguous()
+    A32 = A_log.detach().float().contiguous()
+    dt32 = dt_bias.detach().float().contiguous()
+    g = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    beta = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+    _lib.check(_lib.load().ivl_gdn_gate_fwd(_p(a), _p(b), _p(A32), _p(dt32), _p(g), _p(beta),
+                                            a.numel() // H, H, _stream(a)))
+    return g, beta
+
+
+class ShortConvolution(nn.Module):
+    """Causal depthwise conv1d (+SiLU) with a [N,D,W] raw-input cache, newest last
+    (fla:modules/convolution.py:128-297).  Parameter name/shape match the checkpoint:
+    `weight` [D,1,W].  A given cache is updated IN PLACE and returned.  For (cache given, T>1) the
+    cached inputs are carried in (pip fla 0.4.0 / streaming semantics)."""
+
+    def __init__(self, hidden_size: int, kernel_size: int, bias: bool = False, activation: Optional[str] = "silu",
+                 device=None, dtype=None, **_unused):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("InfiniteVL uses conv_bias=False (configuration_infinitevl.py)")
+        if activation is not None:
+            assert activation in ["silu", "swish"], f"Activation `{activation}` not supported yet."
+        self.hidden_size = hidden_size
+        self.kernel_size = (kernel_size,)
+        self.activation = activation
+        self.weight = nn.Parameter(torch.empty(hidden_size, 1, kernel_size, device=device, dtype=dtype))
+        self.register_parameter("bias", None)
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[torch.Tensor] = None,
+                output_final_state: bool = False, cu_seqlens: Optional[torch.Tensor] = None, **kwargs):
+        _need_gpu(x)
+        if cu_seqlens is not None:
+            raise NotImplementedError("variable-length inputs are not used by InfiniteVL (std:1223)")
+        if mask is not None:
+            x = x.mul(mask.unsqueeze(-1))
+        if x.dtype != torch.bfloat16:
+            raise ValueError(f"ShortConvolution kernel is built for bf16, got {x.dtype}")
+        B, T, D = x.shape
+        W = self.kernel_size[0]
+        x = x.contiguous()
+        state_in = cache
+        if output_final_state and cache is None:
+            cache = torch.empty(B, D, W, dtype=x.dtype, device=x.device)       # zero history, written by the kernel
+        if cache is not None and (cache.dtype != torch.bfloat16 or not cache.is_contiguous()
+                                  or tuple(cache.shape) != (B, D, W)):
+            raise ValueError("conv cache must be a contiguous bf16 [N,D,W] tensor")
+        y = torch.empty_like(x)
+        w = self.weight
+        if w.dtype != torch.bfloat16:
+            w = w.to(torch.bfloat16)
+        _lib.check(_lib.load().ivl_short_conv_fwd(
+            _p(x), _p(w.contiguous()), _p(state_in), _p(y), _p(cache), B, T, D, W,
+            int(self.activation is not None), _stream(x)))
+        return y, cache
+
+    def step(self, x: torch.Tensor, cache: torch.Tensor):
+        return self.forward(x, cache=cache, output_final_state=True)
+
+
+class FusedRMSNormGated(nn.Module):
+    """y = rmsnorm(x) * weight * g * sigmoid(g) over the last dim (256)
+    (fla:modules/fused_norm_gate.py:735-796)."""
+
+    def __init__(self, hidden_size: int, elementwise_affine: bool = True, eps: float = 1e-5,
+                 activation: str = "swish", device=None, dtype=None):
+        super().__init__()
+        if activation not in ("swish", "silu"):
+            raise ValueError(f"Unsupported activation: {activation}")
+        if not elementwise_affine:
+            raise NotImplementedError("InfiniteVL's o_norm is affine")
+        self.hidden_size, self.eps, self.activation = hidden_size, eps, activation
+        self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+        self.register_parameter("bias", None)
+
+    def forward(self, x: torch.Tensor, g: torch.Tensor, residual=None, prenorm=False, residual_in_fp32=False):
+        if residual is not None or prenorm:
+            raise NotImplementedError("residual/prenorm are not used by InfiniteVL (std:1338)")
+        _need_gpu(x, g)
+        if x.dtype != torch.bfloat16:
+            raise ValueError(f"FusedRMSNormGated kernel is built for bf16, got {x.dtype}")
+        N = x.shape[-1]
+        x, g = x.contiguous(), g.contiguous()
+        y = torch.empty_like(x)
+        w = self.weight if self.weight.dtype == torch.bfloat16 else self.weight.to(torch.bfloat16)
+        _lib.check(_lib.load().ivl_rmsnorm_swish_gate_fwd(_p(x), _p(g), _p(w.contiguous()), _p(y),
+                                                          x.numel() // N, N, float(self.eps), _stream(x)))
+        return y
+
+
+# ---------------------------------------------------------------------------------------------
+# sliding-window attention
+# ---------------------------------------------------------------------------------------------
+def apply_mrope_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mrope_section):
+    """M-RoPE on time-major q [B,T,Hq,d] / k [B,T,Hkv,d] in place; cos/sin [3,B,T,d] bf16
+    (std:949-984).  Bit-identical to the reference's eager bf16 arithmetic."""
+    _need_gpu(q, k, cos, sin)
+    B, T, Hq, d = q.shape
+    Hkv = k.shape[2]
+    assert q.is_contiguous() and k.is_contiguous() and q.dtype == k.dtype == torch.bfloat16
+    cos = cos.to(torch.bfloat16).contiguous()
+    sin = sin.to(torch.bfloat16).contiguous()
+    if cos.shape[0] != 3 or tuple(cos.shape[1:]) != (B, T, d):
+        raise ValueError(f"cos/sin must be [3,B,T,d]; got {tuple(cos.shape)}")
+    s0, s1, s2 = (int(s) for s in mrope_section)
+    _lib.check(_lib.load().ivl_mrope_fwd(_p(q), _p(k), _p(cos), _p(sin), B, T, Hq, Hkv, d, s0, s1, s2, _stream(q)))
+    return q, k
+
+
+def swa_forward(
+    q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, *, window: Optional[int], scaling: float,
+    k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
+    pos: int = 0, pos_dev: Optional[torch.Tensor] = None, n_query: Optional[int] = None,
+    layout: str = "bthd",
+) -> torch.Tensor:
+    """Sliding-window GQA attention over (ring cache ++ new keys); returns o [B,T,Hq,d] bf16.
+
+    layout "bthd": q [B,T,Hq,d], k_new/v_new [B,T_new,Hkv,d]; "bhtd": head-major views
+    (any strides with a contiguous last dim are accepted -- no copies are made).
+    `n_query` = T (defaults to q's length); T_new >= T, the first T_new-T new keys being older keys."""
+    _need_gpu(q, k_new, v_new, k_cache, v_cache, pos_dev)
+    if q.dtype != torch.bfloat16 or k_new.dtype != torch.bfloat16 or v_new.dtype != torch.bfloat16:
+        raise ValueError("swa_forward is built for bf16")
+    if layout == "bhtd":
+        q, k_new, v_new = q.transpose(1, 2), k_new.transpose(1, 2), v_new.transpose(1, 2)
+    B, T, Hq, d = q.shape
+    T_new, Hkv = k_new.shape[1], k_new.shape[2]
+    if n_query is not None:
+        assert n_query == T
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    if k_new.stride(-1) != 1 or v_new.stride() != k_new.stride():
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    C = 0
+    if k_cache is not None:
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == torch.bfloat16
+        assert tuple(k_cache.shape[:2]) == (B, Hkv) and k_cache.shape[3] == d
+        C = k_cache.shape[2]
+    o = torch.empty(B, T, Hq, d, dtype=torch.bfloat16, device=q.device)
+    lib = _lib.load()
+    nbytes = lib.ivl_swa_workspace_bytes(B, T, Hq, d)
+    ws = get_workspace(nbytes, q.device, "swa")
+    a = SwaArgs()
+    a.q, a.k_new, a.v_new, a.k_cache, a.v_cache, a.o = (q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
+                                                         k_cache.data_ptr() if C else None,
+                                                         v_cache.data_ptr() if C else None, o.data_ptr())
+    a.q_sb, a.q_st, a.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    a.kn_sb, a.kn_st, a.kn_sh = k_new.stride(0), k_new.stride(1), k_new.stride(2)
+    a.B, a.T, a.T_new, a.Hq, a.Hkv, a.d = B, T, T_new, Hq, Hkv, d
+    a.cache_capacity = C
+    a.window = int(window) if window is not None else 0
+    a.pos = int(pos)
+    a.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
+    a.scaling = float(scaling)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.ivl_swa_fwd(ctypes.byref(a), _stream(q)))
+    return o
+
+
+def swa_cache_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                     pos: int = 0, pos_dev: Optional[torch.Tensor] = None) -> None:
+    """Write the call's new tokens [B,T,Hkv,d] into the ring (slot (pos+t) % C); std:146-172."""
+    _need_gpu(k_new, v_new, k_cache, v_cache)
+    B, T, Hkv, d = k_new.shape
+    if k_new.stride(-1) != 1 or v_new.stride() != k_new.stride():
+        k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    _lib.check(_lib.load().ivl_swa_cache_append(
+        _p(k_new), _p(v_new), k_new.stride(0), k_new.stride(1), k_new.stride(2), _p(k_cache), _p(v_cache),
+        B, T, Hkv, d, k_cache.shape[2], int(pos), _p(pos_dev), _stream(k_new)))
+
+
+def counter_add(counter: torch.Tensor, delta: int) -> None:
+    _lib.check(_lib.load().ivl_counter_add(_p(counter), int(delta), _stream(counter)))
+
+
+def swa_attention_interface(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                            scaling: Optional[float] = None, sliding_window: Optional[int] = None,
+                            position_ids=None, **kwargs):
+    """Drop-in for ALL_ATTENTION_FUNCTIONS["flash_attention_2"] at std:1097-1108:
+    query [B,Hq,T,d], key/value [B,Hkv,S,d] (S >= T, already concatenated with the cached keys);
+    causal, bottom-right aligned, left window `sliding_window`; the mask tensor is ignored exactly as
+    FlashAttention-2 ignores it for an unpadded batch.  Returns (out [B,T,Hq,d], None)."""
+    if dropout:
+        raise NotImplementedError("attention dropout is a training feature; the hot path is inference")
+    if scaling is None:
+        scaling = query.shape[-1] ** -0.5
+    out = swa_forward(query, key, value, window=sliding_window, scaling=scaling, layout="bhtd")
+    return out, None
