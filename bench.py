@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): prefill tok/s + decode tok/s, InfiniteVL-3B @128K sequence.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): the full 36-layer InfiniteVL-3B decoder (random-init bf16 weights of
+the shipped config.json -- no checkpoint offline), streaming prefill in 256-token chunk steps with the
+sliding window overridden to 4096, one hipGraph replay per step, one sequence per GPU (batch-sharded
+replicas; the only collective is the final logits all-gather).  A "step" = one 256-token chunk through
+all 36 layers (27 Gated DeltaNet + 9 SWA mixers on the gfx950 kernels of this repo, the projections/MLP
+on stock rocBLAS/hipBLASLt).  Untimed setup fills the SWA window (17 steps) so that every warm-up and
+timed step is a steady-state full-window step; K=512 timed steps = 131072 tokens (the default).
+After the timed prefill region a decode leg (graph-captured greedy single-token steps at that context)
+is timed separately and reported as `decode_tok_s`.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant hot-path kernel, measured live with
+HIP events on the launch stream), `kernels` (all hot-path kernels), `cpu_baseline` (oracle on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=256, help="tokens per streaming step")
+    ap.add_argument("--window", type=int, default=4096)
+    ap.add_argument("--decode-steps", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=36, help="debug only; the reported config is 36")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, stream):
+    """Average duration of `fn` (which launches on `stream`) measured with HIP events on that stream."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_timings(device, chunk, window):
+    """Per-launch time of every hot-path kernel at the bench shapes (B=1, T=chunk, real head shapes,
+    full window), each measured live with HIP events on the stream it is launched on."""
+    from infinitevl_amd import ops
+    st = torch.cuda.current_stream(device)
+    B, T, H, K, V, Hq, Hkv, d = 1, chunk, 16, 128, 256, 16, 2, 128
+    g_ = torch.Generator(device=device).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=device, generator=g_).to(torch.bfloat16)  # noqa: E731
+    q, k, v = rn(B, T, H, K), rn(B, T, H, K), rn(B, T, H, V)
+    beta = torch.rand(B, T, H, device=device, generator=g_).to(torch.bfloat16)
+    g = torch.nn.functional.logsigmoid(torch.randn(B, T, H, device=device, generator=g_))
+    state = (torch.randn(B, H, K, V, device=device, generator=g_)).to(torch.bfloat16)
+    res = {}
+
+    t = event_time_ms(lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state,
+                                                         use_qk_l2norm_in_kernel=True, final_state_out=state), 50, st)
+    gdn_bytes = 24672.0 * T + 2 * H * K * V * 4          # per-token bytes + fp32 state r+w per call
+    res["gdn_chunk(prepare+scan)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=gdn_bytes,
+                                          achieved=gdn_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    # SWA prefill step: T queries over a full ring (W-1 cached keys) + T new keys
+    C = window - 1
+    kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
+    pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
+    qs, kn, vn = rn(B, T, Hq, d), rn(B, T, Hkv, d), rn(B, T, Hkv, d)
+    t = event_time_ms(lambda: ops.swa_forward(qs, kn, vn, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
+                                              pos_dev=pos_dev), 50, st)
+    swa_flops = 4.0 * Hq * d * window * T                 # 8192*min(p+1,W) FLOP/token/layer
+    res["swa_prefill"] = dict(ms=t, launches_per_step=9, bound="mfma", alg_flops=swa_flops,
+                              achieved=swa_flops / (t * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+    t = event_time_ms(lambda: ops.swa_cache_append(kn, vn, kc, vc, pos_dev=pos_dev), 50, st)
+    res["swa_cache_append"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=4.0 * T * Hkv * d * 2,
+                                   achieved=4.0 * T * Hkv * d * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    # decode-shape kernels
+    q1, k1, v1 = rn(B, 1, H, K), rn(B, 1, H, K), rn(B, 1, H, V)
+    b1 = torch.rand(B, 1, H, device=device, generator=g_).to(torch.bfloat16)
+    g1 = torch.nn.functional.logsigmoid(torch.randn(B, 1, H, device=device, generator=g_))
+    t = event_time_ms(lambda: ops.fused_recurrent_gated_delta_rule(q1, k1, v1, g1, b1, initial_state=state,
+                                                                   use_qk_l2norm_in_kernel=True, final_state_out=state), 100, st)
+    rec_bytes = 24672.0 + 2 * H * K * V * 2               # bf16 cache state read + write
+    res["gdn_recurrent(decode)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=rec_bytes,
+                                        achieved=rec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    qd = rn(B, 1, Hq, d)
+    kd1, vd1 = rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
+    t = event_time_ms(lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
+                                              pos_dev=pos_dev), 100, st)
+    dec_bytes = 1024.0 * window                           # 1024*min(p+1,W) B/token/layer
+    res["swa_decode"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=dec_bytes,
+                             achieved=dec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    # bandwidth-bound helpers at T=chunk
+    x8 = rn(B, T, 8192)
+    conv = ops.ShortConvolution(8192, 4).to(device, torch.bfloat16)
+    cst = rn(B, 8192, 4)
+    t = event_time_ms(lambda: conv(x8, cache=cst, output_final_state=True), 50, st)
+    res["short_conv(q+k+v channels)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=2.0 * T * 8192 * 2,
+                                             achieved=2.0 * T * 8192 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    norm = ops.FusedRMSNormGated(256).to(device, torch.bfloat16)
+    xo, go = rn(B, T, H, V), rn(B, T, H, V)
+    t = event_time_ms(lambda: norm(xo, go), 50, st)
+    res["rmsnorm_swish_gate"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=3.0 * T * H * V * 2,
+                                     achieved=3.0 * T * H * V * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    for r in res.values():
+        r["frac"] = r["achieved"] / r["peak"]
+    return res
+
+
+def cpu_baseline(chunk, window):
+    """Oracle (CPU restatement of the path = BASELINE.md section 3 'reference CPU eager path') on the host cores:
+    ONE 4-layer period (1 SWA + 3 GDN decoder layers, real InfiniteVL-3B shapes, fp32 weights) for one
+    `chunk`-token step with a full window, extrapolated x9 to the 36-layer stack."""
+    from oracle import model as omodel
+    from oracle.cache import SwaCounters
+    torch.set_num_threads(os.cpu_count() or 1)
+    oc = omodel.OracleConfig(sliding_window=window, layer_types=["sliding_attention"] + ["linear_attention"] * 3)
+    params = omodel.random_params(oc, seed=0)
+    cache = omodel.new_cache(oc)
+    # full window without paying for the fill: plant W-1 cached keys directly
+    g_ = torch.Generator().manual_seed(1)
+    cache[0].k = torch.randn(1, 2, window - 1, 128, generator=g_)
+    cache[0].v = torch.randn(1, 2, window - 1, 128, generator=g_)
+    cache[0].counters = SwaCounters(window, size=window - 1, cumulative_length=4 * window)
+    x = torch.randn(1, chunk, oc.hidden_size, generator=g_) * 0.02
+    pid = torch.arange(4 * window, 4 * window + chunk)[None, None, :].expand(3, 1, chunk).contiguous()
+    omodel.text_stack(params, x, pid, oc, cache)                      # warm-up (also flips the GDN `start` flags)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        pid = pid + chunk
+        omodel.text_stack(params, x, pid, oc, cache)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 8:
+            break
+    per_period = el / n
+    return dict(value=chunk / (per_period * 9.0), unit="tok/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/model.py on host CPU: one 4-layer period (1 SWA + 3 GDN decoder layers, fp32, real "
+                       f"InfiniteVL-3B shapes) x {n} steps of {chunk} tokens with a full {window}-key window, "
+                       f"{per_period:.3f} s per period-step, extrapolated x9 to 36 layers")
+
+
+def main():
+    args = parse()
+    from infinitevl_amd import dist as ivd
+    rank, world, local_rank = ivd.init_distributed("nccl")
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import infinitevl_amd
+    infinitevl_amd.load_library()
+    from infinitevl_amd.harness import GraphedDecode, GraphedStep, InfiniteVLTextConfig, InfiniteVLTextStack
+
+    cfg = InfiniteVLTextConfig(sliding_window=args.window, num_hidden_layers=args.layers)
+    with torch.device(device):
+        torch.set_default_dtype(torch.bfloat16)
+        model = InfiniteVLTextStack(cfg)
+        torch.set_default_dtype(torch.float32)
+    model = model.to(torch.bfloat16).eval()
+    model.init_weights_(seed=0)
+    B_local = 1                                    # one sequence per GPU (weak scaling over the batch)
+    cache = model.allocate_inference_cache(B_local)
+    T = args.chunk
+    gen = torch.Generator(device=device).manual_seed(100 + rank)
+    frames = [(torch.randn(B_local, T, cfg.hidden_size, device=device, generator=gen) * 0.02).to(torch.bfloat16)
+              for _ in range(4)]
+
+    step = GraphedStep(model, cache, B_local, T, logits_to_keep=1)
+    step.capture()
+    # untimed setup: fill the sliding window so every later step is a steady-state step
+    fill = (args.window - 1 + T - 1) // T + 1
+    for i in range(fill):
+        step.step(frames[i % 4])
+    for i in range(args.warmup):
+        step.step(frames[i % 4])
+    ivd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step.step(frames[i % 4])
+    torch.cuda.synchronize()
+    ivd.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = ivd.max_over_ranks(elapsed, device)
+    tokens_global = args.steps * T * B_local * world
+    ctx_tokens = cache.get_seq_length()
+
+    # the path's only collective: gather the last-position logits of every sequence
+    _, logits = step.hidden, step.logits
+    all_logits = ivd.gather_last_logits(logits[:, -1].float().contiguous(), [B_local] * world)
+    finite = bool(torch.isfinite(all_logits).all())
+
+    # ---- decode leg (separately timed) ------------------------------------------------------------
+    dec = GraphedDecode(model, cache, B_local)
+    dec.token.copy_(logits[:, -1].argmax(-1, keepdim=True))
+    dec.capture()
+    for _ in range(4):
+        dec.step()
+    ivd.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.decode_steps):
+        dec.step()
+    torch.cuda.synchronize()
+    ivd.barrier()
+    dec_elapsed = ivd.max_over_ranks(time.perf_counter() - t1, device)
+    mem_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
+
+    kernels, cpu = None, None
+    if rank == 0 and not args.no_kernel_timing:
+        kernels = kernel_timings(device, T, args.window)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(T, args.window)
+    ivd.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "prefill tok/s + decode tok/s, InfiniteVL-3B @128K seq",
+            "value": tokens_global / elapsed, "unit": "tok/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "decode_tok_s": args.decode_steps * B_local * world / dec_elapsed,
+            "decode_ms_per_token": dec_elapsed / args.decode_steps * 1e3,
+            "config": {
+                "workload": f"InfiniteVL-3B ({args.layers} layers: 9 SWA + 27 Gated DeltaNet, random-init bf16) streaming "
+                            f"prefill, {T}-token hipGraph chunk steps, SWA window {args.window} (full), then greedy decode "
+                            f"at the reached context",
+                "global_batch": B_local * world, "seq_len": ctx_tokens, "tokens_timed": tokens_global,
+                "parallelism": f"dp{world} (batch-sharded replicas, one logits all-gather)",
+                "decode_steps": args.decode_steps, "window_fill_steps_untimed": fill,
+            },
+            "logits_finite": finite, "peak_mem_gib": round(mem_gb, 2),
+        }
+        if kernels is not None:
+            def step_ms(r):
+                return r["ms"] * r["launches_per_step"]
+            prefill_kernels = {k: v for k, v in kernels.items() if "decode" not in k}
+            dom = max(prefill_kernels, key=lambda k: step_ms(prefill_kernels[k]))
+            r = kernels[dom]
+            out["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
+                               "unit": r["unit"], "frac": r["frac"], "traffic": None,
+                               "avg_launch_ms": r["ms"], "launches_per_step": r["launches_per_step"]}
+            out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                              for k, v in kernels.items()}
+            out["hot_path_ms_per_step"] = sum(step_ms(v) for v in prefill_kernels.values())
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

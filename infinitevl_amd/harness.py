@@ -127,19 +127,19 @@ class InfiniteVLTextStack(nn.Module):
 
     @torch.no_grad()
     def init_weights_(self, seed: int = 0, std: float = 0.02) -> "InfiniteVLTextStack":
-        """Random init in the spirit of the reference's initializer_range=0.02 (no checkpoint offline)."""
-        gen = torch.Generator(device="cpu").manual_seed(seed)
+        """Random init in the spirit of the reference's initializer_range=0.02 (there is no checkpoint
+        offline).  Works in place on whatever device/dtype the parameters live on."""
+        dev = next(self.parameters()).device
+        gen = torch.Generator(device=dev).manual_seed(seed)
         for name, p_ in self.named_parameters():
             if name.endswith("A_log") or name.endswith("dt_bias"):
                 continue
             if "layernorm" in name or name.endswith("norm.weight"):
                 p_.fill_(1.0)
             elif "conv1d" in name:
-                p_.copy_(torch.randn(p_.shape, generator=gen) * 0.3)
-            elif name.endswith(".bias"):
-                p_.copy_(torch.randn(p_.shape, generator=gen) * std)
+                p_.normal_(0.0, 0.3, generator=gen)
             else:
-                p_.copy_(torch.randn(p_.shape, generator=gen) * std)
+                p_.normal_(0.0, std, generator=gen)
         return self
 
     def allocate_inference_cache(self, batch_size: int = 1, dtype: Optional[torch.dtype] = None,
@@ -225,6 +225,51 @@ class GraphedStep:
         self.graph.replay()
         self.cache.advance(self.T)
         return self.hidden, self.logits
+
+
+class GraphedDecode:
+    """hipGraph-captured greedy single-token step: embed(token) -> stack -> argmax -> token buffer
+    (the demo's eager loop, demo:399-422, made replayable: token and position stay on the device)."""
+
+    def __init__(self, model: InfiniteVLTextStack, cache: StaticCachePrealloc, batch_size: int, warmup: int = 2):
+        p_ = next(model.parameters())
+        self.model, self.cache, self.B = model, cache, batch_size
+        self.token = torch.zeros(batch_size, 1, dtype=torch.int64, device=p_.device)
+        start = cache.get_seq_length()
+        self.position_ids = torch.full((3, batch_size, 1), start, dtype=torch.int64, device=p_.device)
+        self.logits = None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._warmup = warmup
+
+    def _run(self):
+        _, lg = self.model(input_ids=self.token, position_ids=self.position_ids, past_key_values=self.cache,
+                           logits_to_keep=1)
+        self.token.copy_(lg[:, -1].argmax(-1, keepdim=True))
+        self.position_ids.add_(1)
+        return lg
+
+    def capture(self) -> None:
+        saved, saved_pos, saved_tok = self.cache.clone(), self.position_ids.clone(), self.token.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(self._warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits = self._run()
+        self.cache.copy_from(saved)
+        self.position_ids.copy_(saved_pos)
+        self.token.copy_(saved_tok)
+
+    def step(self):
+        """One decode step; the new token is left in self.token (device)."""
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        self.cache.advance(1)
+        return self.token
 
 
 @torch.no_grad()

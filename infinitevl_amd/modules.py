@@ -28,15 +28,20 @@ class InfiniteVLRotaryEmbedding(nn.Module):
         self.config = config
         head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
         theta = float(getattr(config, "rope_theta", 1e6))
-        inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
-        self.register_buffer("inv_freq", inv_freq.to(device) if device is not None else inv_freq, persistent=False)
+        # kept as a plain fp32 tensor (not a buffer): `module.to(bfloat16)` must not round the frequencies
+        self._inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
         self.attention_scaling = 1.0
+
+    @property
+    def inv_freq(self) -> torch.Tensor:
+        return self._inv_freq
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, position_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        inv = self.inv_freq[None, None, :, None].float().expand(3, position_ids.shape[1], -1, 1)
-        pos = position_ids[:, :, None, :].float()
-        freqs = (inv @ pos).transpose(2, 3)
+        if self._inv_freq.device != x.device:
+            self._inv_freq = self._inv_freq.to(x.device)
+        # outer product position x frequency in fp32 (std:920-925 does it as a K=1 matmul)
+        freqs = position_ids[..., None].float() * self._inv_freq
         emb = torch.cat((freqs, freqs), dim=-1)
         return (emb.cos() * self.attention_scaling).to(x.dtype), (emb.sin() * self.attention_scaling).to(x.dtype)
 

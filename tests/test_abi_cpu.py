@@ -1,0 +1,266 @@
+"""CPU (-m "not gpu"): the C-ABI library builds, loads and exports every symbol include/ivl_hip.h
+declares; argument validation returns error codes without touching a GPU; the host-side mirror of the
+reference interface (cache integer bookkeeping, error behaviour, parameter names) matches the
+reference.  No compute call is made here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import cache as ocache
+
+
+@pytest.fixture(scope="session")
+def lib():
+    so = os.path.join(ROOT, "infinitevl_amd", "libivl_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    import infinitevl_amd
+    return infinitevl_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ivl_hip.h")).read()
+    declared = set(re.findall(r"\b(ivl_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("ivl_swa_args")
+    assert len(declared) >= 13
+    from infinitevl_amd._lib import EXPORTED_SYMBOLS
+    assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ivl_abi_version() == 1
+
+
+def test_argument_validation_returns_codes(lib):
+    from infinitevl_amd import _lib
+    rc = lib.ivl_short_conv_fwd(None, None, None, None, None, 1, 1, 8, 4, 1, None)
+    assert rc == _lib.IVL_ERR_INVALID_ARG and b"NULL" in lib.ivl_last_error()
+    one = ctypes.c_void_p(0x1000)       # never dereferenced: validation fails first
+    assert lib.ivl_short_conv_fwd(one, one, None, one, None, 1, 1, 8, 3, 1, None) == _lib.IVL_ERR_UNSUPPORTED
+    assert lib.ivl_short_conv_fwd(one, one, None, one, None, 1, 1, 12, 4, 1, None) == _lib.IVL_ERR_UNSUPPORTED
+    assert lib.ivl_short_conv_fwd(one, one, None, one, None, 0, 1, 8, 4, 1, None) == _lib.IVL_ERR_INVALID_ARG
+    assert lib.ivl_gdn_recurrent_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 1, 2, 64, 256, 1.0, 1, None) \
+        == _lib.IVL_ERR_UNSUPPORTED                                        # K != 128
+    assert lib.ivl_gdn_chunk_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 100, 2, 128, 256, 1.0, 1,
+                                 one, 16, None) == _lib.IVL_ERR_WORKSPACE
+    assert lib.ivl_rmsnorm_swish_gate_fwd(one, one, one, one, 4, 128, 1e-5, None) == _lib.IVL_ERR_UNSUPPORTED
+    assert lib.ivl_mrope_fwd(one, one, one, one, 1, 1, 2, 1, 128, 16, 24, 23, None) == _lib.IVL_ERR_UNSUPPORTED
+    assert lib.ivl_swa_fwd(None, None) == _lib.IVL_ERR_INVALID_ARG
+    a = _lib.SwaArgs()
+    a.q = a.k_new = a.v_new = a.o = 0x1000
+    a.B, a.T, a.T_new, a.Hq, a.Hkv, a.d = 1, 4, 4, 16, 2, 64
+    assert lib.ivl_swa_fwd(ctypes.byref(a), None) == _lib.IVL_ERR_UNSUPPORTED   # head_dim != 128
+    a.d, a.Hq = 128, 3
+    assert lib.ivl_swa_fwd(ctypes.byref(a), None) == _lib.IVL_ERR_INVALID_ARG   # Hq % Hkv
+    with pytest.raises(ValueError):
+        _lib.check(_lib.IVL_ERR_INVALID_ARG)
+    with pytest.raises(_lib.IvlError):
+        _lib.check(_lib.IVL_ERR_LAUNCH)
+
+
+def test_workspace_sizes(lib):
+    per_chunk = 90624
+    assert lib.ivl_gdn_chunk_workspace_bytes(1, 256, 16, 128, 256) == 16 * 4 * per_chunk
+    assert lib.ivl_gdn_chunk_workspace_bytes(2, 65, 3, 128, 256) == 2 * 3 * 2 * per_chunk
+    # long calls are processed in 64-chunk segments: bounded workspace + fp32 state carry
+    assert lib.ivl_gdn_chunk_workspace_bytes(1, 131072, 16, 128, 256) == 16 * 64 * per_chunk + 16 * 128 * 256 * 4
+    assert lib.ivl_gdn_chunk_workspace_bytes(1, 256, 16, 64, 256) == 0
+    assert lib.ivl_swa_workspace_bytes(1, 4096, 16, 128) <= (1 << 20) * 600
+    assert lib.ivl_swa_workspace_bytes(1, 1, 16, 64) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from infinitevl_amd import ops
+    z = torch.zeros(1, 4, 2, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.chunk_gated_delta_rule(z, z, torch.zeros(1, 4, 2, 256, dtype=torch.bfloat16), torch.zeros(1, 4, 2),
+                                   torch.zeros(1, 4, 2, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.swa_forward(z, z, z, window=8, scaling=1.0)
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through the oracle (or any CPU fallback)."""
+    code = "import sys; import infinitevl_amd, infinitevl_amd.harness, infinitevl_amd.dist; " \
+           "print(int(any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)))"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, check=True)
+    assert out.stdout.strip().endswith("0")
+    for fn in os.listdir(os.path.join(ROOT, "infinitevl_amd")):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "infinitevl_amd", fn)).read(), fn
+
+
+# ---------------------------------------------------------------------------------------------
+# cache: integer bookkeeping (bit-exact vs the reference traces) and error behaviour
+# ---------------------------------------------------------------------------------------------
+class _Cfg:
+    num_key_value_heads, num_attention_heads, head_dim, hidden_size = 2, 4, 16, 64
+    sliding_window, max_position_embeddings = 8, 4096
+    num_linear_heads = num_linear_key_value_heads = 4
+    linear_head_dim, conv_size, use_short_conv, expand_v = 16, 4, True, 2
+    layer_types = ["sliding_attention", "linear_attention", "linear_attention", "linear_attention"]
+    num_hidden_layers = 4
+
+
+def test_swa_layer_counters_match_reference_traces():
+    from infinitevl_amd.cache import StaticSlidingWindowLayerPrealloc
+    z = load_golden("cache_traces")
+    for key in sorted(k[:-6] for k in z if k.endswith("_steps")):
+        steps, W = z[key + "_steps"].tolist(), int(z[key + "_W"])
+        cfg = _Cfg()
+        cfg.sliding_window = W
+        layer = StaticSlidingWindowLayerPrealloc(config=cfg, batch_size=1, device="cpu", dtype=torch.bfloat16)
+        assert layer.capacity == W - 1 and tuple(layer._buf_keys.shape) == (1, 2, W - 1, 16)
+        ref = z[key + "_trace"].numpy()
+        pos = 0
+        for i, T in enumerate(steps):
+            full_len = layer.size + T
+            layer.advance(T)                       # host-side effect of one call (kernels not involved)
+            kv_len, kv_off = layer.get_mask_sizes(torch.arange(pos, pos + T))
+            assert (full_len, layer.size, layer.cumulative_length, kv_len, kv_off) == tuple(ref[i].tolist()), (key, i)
+            assert layer.get_seq_length() == layer.cumulative_length
+            pos += T
+    layer = StaticSlidingWindowLayerPrealloc(config=_Cfg(), batch_size=2, device="cpu", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        layer.batch_repeat_interleave(2)
+    with pytest.raises(RuntimeError):
+        layer.batch_select_indices(torch.arange(3))
+    layer.batch_repeat_interleave(1)
+    layer.advance(9)
+    with pytest.raises(ValueError, match="Cropping is forbidden"):
+        layer.crop(3)
+    bad = _Cfg()
+    bad.sliding_window, bad.max_position_embeddings = 0, 0
+    with pytest.raises(ValueError):
+        StaticSlidingWindowLayerPrealloc(config=bad, batch_size=1)
+
+
+def test_swa_ring_chronological_view_matches_reference_tail():
+    """`keys` must present the cached tokens oldest-first exactly like the reference's linear tail
+    buffer (fixture: positions held after each call of the probed trace)."""
+    from infinitevl_amd.cache import StaticSlidingWindowLayerPrealloc
+    z = load_golden("cache_traces")
+    layer = StaticSlidingWindowLayerPrealloc(config=_Cfg(), batch_size=1, device="cpu", dtype=torch.float32)
+    pos, off = 0, 0
+    for T, n in zip([5, 1, 1, 1, 6, 1, 20], z["W8_tail_lengths"].tolist()):
+        for t in range(max(0, T - layer.capacity), T):          # what ivl_swa_cache_append writes
+            layer._buf_keys[:, :, (pos + t) % layer.capacity, :] = float(pos + t)
+        layer.advance(T)
+        pos += T
+        got = layer.keys[0, 0, :, 0].numpy()
+        assert np.array_equal(got, z["W8_tail_positions"].numpy()[off:off + n])
+        off += n
+
+
+def test_linear_layer_protocol_and_errors():
+    from infinitevl_amd.cache import StaticLinearLayerPrealloc
+    layer = StaticLinearLayerPrealloc(config=_Cfg(), batch_size=2, device="cpu", dtype=torch.float32, zero_init=True)
+    assert tuple(layer.recurrent_state.shape) == (2, 4, 16, 32)
+    assert tuple(layer.conv_state_v.shape) == (2, 4 * 32, 4)
+    ref = ocache.LinearCounters()
+    (cq, ck, cv), rec = layer.update(cache_kwargs={"op": "get"})
+    assert cq is None and rec is None and ref.get() is False           # first call returns Nones (std:298-300)
+    new = torch.ones(2, 4, 16, 32)
+    layer.update(conv_state=(torch.ones(2, 64, 4), None, None), recurrent_state=new, cache_kwargs={"op": "set", "delta_len": 7})
+    ref.set(7)
+    assert layer.seq_len == ref.seq_len == 7 and torch.equal(layer.recurrent_state, new)
+    (cq, _, _), rec = layer.update(cache_kwargs={"op": "get"})
+    assert rec is layer.recurrent_state and float(cq.sum()) == 2 * 64 * 4
+    with pytest.raises(RuntimeError, match="recurrent_state shape changed"):
+        layer.update(recurrent_state=torch.ones(2, 4, 16, 16), cache_kwargs={"op": "set"})
+    with pytest.raises(RuntimeError, match="conv_q shape changed"):
+        layer.update(conv_state=(torch.ones(2, 60, 4), None, None), cache_kwargs={"op": "set"})
+    assert layer.get_mask_sizes(torch.arange(3)) == (10, 0)
+    layer.crop(-2)
+    assert layer.seq_len == 5
+
+
+def test_aggregate_cache_dispatch_clone_copy():
+    from infinitevl_amd.cache import (StaticCachePrealloc, StaticLinearLayerPrealloc,
+                                      StaticSlidingWindowLayerPrealloc)
+    c = StaticCachePrealloc(config=_Cfg(), batch_size=1, device="cpu", dtype=torch.bfloat16, zero_init=True)
+    assert [type(l) for l in c.layers] == [StaticSlidingWindowLayerPrealloc] + [StaticLinearLayerPrealloc] * 3
+    for name in ("is_sliding", "_buf_keys", "_buf_values", "keys", "values", "size", "cumulative_length", "capacity"):
+        assert hasattr(c.layers[0], name)          # attribute names read by the demo's clone (demo:123-146)
+    for name in ("conv_state_q", "conv_state_k", "conv_state_v", "recurrent_state", "seq_len", "start"):
+        assert hasattr(c.layers[1], name)          # demo:147-158
+    c.advance(5)
+    c.layers[1].recurrent_state.fill_(3.0)
+    d = c.clone()
+    d.advance(2)
+    d.layers[1].recurrent_state.fill_(4.0)
+    assert c.get_seq_length() == 5 and d.get_seq_length() == 7
+    assert float(c.layers[1].recurrent_state[0, 0, 0, 0]) == 3.0
+    c.copy_from(d)
+    assert c.get_seq_length() == 7 and float(c.layers[1].recurrent_state[0, 0, 0, 0]) == 4.0
+    assert c.layers[1].recurrent_state.data_ptr() != d.layers[1].recurrent_state.data_ptr()
+
+
+def test_module_parameter_names_match_reference_checkpoint_layout():
+    """state_dict keys/shapes of the drop-in modules == the reference modules' (fixture holds the
+    reference state_dict of a tiny config: std:1019-1022, 1161-1213)."""
+    from infinitevl_amd.harness import InfiniteVLDecoderLayer, InfiniteVLTextConfig
+    z = load_golden("tiny_stack")
+    lt = [str(x) for x in z["layer_types"]]
+    cfg = InfiniteVLTextConfig(vocab_size=97, hidden_size=64, intermediate_size=96, num_hidden_layers=4,
+                               num_attention_heads=4, num_key_value_heads=2, head_dim=16, sliding_window=8,
+                               layer_types=lt, num_linear_heads=4, num_linear_key_value_heads=4, linear_head_dim=16,
+                               rope_scaling={"mrope_section": [2, 3, 3]})
+    for i in range(4):
+        ours = {k: tuple(v.shape) for k, v in InfiniteVLDecoderLayer(cfg, i).state_dict().items()}
+        ref = {k[len(f"w.layers.{i}."):]: tuple(v.shape) for k, v in z.items() if k.startswith(f"w.layers.{i}.")}
+        assert ours == ref, (i, set(ours) ^ set(ref))
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU host logic on CPU: gloo, world_size 2
+# ---------------------------------------------------------------------------------------------
+def test_shard_batch_properties():
+    from infinitevl_amd.dist import shard_batch
+    for world in (1, 2, 3, 8):
+        for gb in (0, 1, 7, 8, 19):
+            spans = [shard_batch(gb, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == gb
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_batch(4, 2, 2)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from infinitevl_amd import dist as ivd
+    r, w, _ = ivd.init_distributed("gloo")
+    counts = [ivd.shard_batch(5, i, w)[1] for i in range(w)]          # ragged: 3 + 2
+    first, cnt = ivd.shard_batch(5, r, w)
+    local = torch.arange(first, first + cnt, dtype=torch.float32)[:, None] * torch.ones(1, 11)
+    full = ivd.gather_last_logits(local, counts)
+    ivd.barrier()
+    mx = ivd.max_over_ranks(1.0 + r, torch.device("cpu"))
+    q.put((r, full[:, 0].tolist(), mx))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_gather_and_max():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for r, col, mx in res:
+        assert col == [0.0, 1.0, 2.0, 3.0, 4.0] and mx == 2.0

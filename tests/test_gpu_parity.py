@@ -1,0 +1,398 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (a) the committed golden fixtures that
+were produced by executing the reference, (b) the CPU oracle on the same seeded inputs, (c) size-
+independent properties at BASELINE.json's full sizes.
+
+Stated tolerances (SURVEY.md section 4 / fla:ops/utils/testing.py: RMS-relative error):
+  * bf16-I/O kernels vs an exact fp32 reference result:            <= 5e-3  (fla's fwd convention)
+  * same vs the oracle run with the reference's bf16 rounding points: <= 5e-4 (outputs), 1e-5..2e-3 (state,
+    2e-3 only when the state itself is stored in bf16)
+  * integers (window band, counters, ring placement) and M-RoPE: bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rms_rel
+from oracle import gdn as ogdn
+from oracle import swa as oswa
+from tools import parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import infinitevl_amd
+    infinitevl_amd.load_library()          # fails loudly when the HIP extension is missing
+    yield
+
+
+# ---------------------------------------------------------------------------------------------
+# Gated DeltaNet operator
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["rec_T1_h0", "rec_T7_h0", "rec_T64", "chunk_T65_h0", "chunk_T160", "chunk_T256_h0"])
+def test_gdn_golden_reference_vectors(name):
+    from infinitevl_amd import ops
+    z = load_golden("gdn_" + name)
+    fn = ops.fused_recurrent_gated_delta_rule if name.startswith("rec") else ops.chunk_gated_delta_rule
+    h0 = z.get("h0")
+    o, ht = fn(bf(z["q"]).to(DEV), bf(z["k"]).to(DEV), bf(z["v"]).to(DEV), z["g"].to(DEV), bf(z["beta"]).to(DEV),
+               initial_state=None if h0 is None else h0.to(DEV), output_final_state=True, use_qk_l2norm_in_kernel=True)
+    assert ht.dtype == torch.float32 and o.dtype == torch.bfloat16
+    assert rms_rel(z["o"], o.float().cpu()) < 5e-3
+    assert rms_rel(z["ht"], ht.cpu()) < 5e-3
+
+
+def test_gdn_golden_chained_bf16_state():
+    """Q5: state rounded to the cache dtype between calls (kernel writes bf16 in place)."""
+    from infinitevl_amd import ops
+    z = load_golden("gdn_chunk_chained_2x128_bf16state")
+    state = bf(z["h0"]).to(DEV)
+    outs = []
+    for a, b in ((0, 128), (128, 256)):
+        o, _ = ops.chunk_gated_delta_rule(bf(z["q"][:, a:b]).to(DEV), bf(z["k"][:, a:b]).to(DEV), bf(z["v"][:, a:b]).to(DEV),
+                                          z["g"][:, a:b].to(DEV), bf(z["beta"][:, a:b]).to(DEV), initial_state=state,
+                                          use_qk_l2norm_in_kernel=True, final_state_out=state)
+        outs.append(o.float().cpu())
+        if a == 0:
+            assert rms_rel(z["s_mid"], state.float().cpu()) < 5e-3
+    assert rms_rel(z["o"], torch.cat(outs, 1)) < 5e-3
+    assert rms_rel(z["ht"], state.float().cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("mode,B,T,H,h0,sd,inplace", [
+    ("recurrent", 1, 1, 2, True, torch.float32, False), ("recurrent", 2, 7, 3, True, torch.float32, False),
+    ("recurrent", 1, 64, 2, False, torch.float32, False), ("recurrent", 1, 33, 16, True, torch.bfloat16, True),
+    ("recurrent", 1, 70, 2, True, torch.float32, False),
+    ("chunk", 1, 64, 1, False, torch.float32, False), ("chunk", 1, 65, 2, True, torch.float32, False),
+    ("chunk", 1, 1, 2, True, torch.float32, False), ("chunk", 1, 30, 2, True, torch.float32, False),
+    ("chunk", 2, 256, 2, True, torch.float32, False), ("chunk", 1, 257, 16, True, torch.bfloat16, True),
+    ("chunk", 1, 1000, 2, False, torch.float32, False),
+])
+def test_gdn_vs_oracle(mode, B, T, H, h0, sd, inplace):
+    r = parity.gdn_op_parity(DEV, mode, B, T, H, seed=T + H, with_h0=h0, state_dtype=sd, inplace_state=inplace)
+    assert r["finite"] == 1.0
+    assert r["o_vs_exact"] < 5e-3 and r["s_vs_exact"] < 5e-3, r
+    assert r["o_vs_bf16model"] < 5e-4, r
+    assert r["s_vs_bf16model"] < (2.5e-3 if sd == torch.bfloat16 else 1e-4), r
+
+
+def test_gdn_long_call_uses_segments_and_matches_chained_calls():
+    """Full-size property (H=16, T=8192+100 > one 4096-token workspace segment): one long call ==
+    the same tokens fed as 256-token calls with the fp32 state carried (split invariance)."""
+    from infinitevl_amd import ops
+    B, T, H = 1, 8292, 16
+    q, k, v, g, beta, h0 = parity.gdn_inputs(5, B, T, H)
+    qd, kd, vd, bd, gd = bf(q).to(DEV), bf(k).to(DEV), bf(v).to(DEV), bf(beta).to(DEV), g.to(DEV)
+    o1, s1 = ops.chunk_gated_delta_rule(qd, kd, vd, gd, bd, initial_state=h0.to(DEV), output_final_state=True,
+                                        use_qk_l2norm_in_kernel=True)
+    st = h0.to(DEV)
+    outs = []
+    for a in range(0, T, 256):
+        b_ = min(T, a + 256)
+        o, st = ops.chunk_gated_delta_rule(qd[:, a:b_], kd[:, a:b_], vd[:, a:b_], gd[:, a:b_], bd[:, a:b_],
+                                           initial_state=st, output_final_state=True, use_qk_l2norm_in_kernel=True)
+        outs.append(o)
+    o2 = torch.cat(outs, 1)
+    assert torch.isfinite(o1.float()).all()
+    # chunk boundaries coincide (256 = 4 chunks) -> identical arithmetic
+    assert torch.equal(o1, o2) and torch.equal(s1, st)
+
+
+def test_gdn_chunk_equals_recurrent_kernel_at_full_width():
+    """Two independent kernels, same function (H=16 heads, T=64: the mode-switch boundary, Q7)."""
+    from infinitevl_amd import ops
+    q, k, v, g, beta, h0 = parity.gdn_inputs(9, 2, 64, 16)
+    args = (bf(q).to(DEV), bf(k).to(DEV), bf(v).to(DEV), g.to(DEV), bf(beta).to(DEV))
+    o1, s1 = ops.chunk_gated_delta_rule(*args, initial_state=h0.to(DEV), output_final_state=True, use_qk_l2norm_in_kernel=True)
+    o2, s2 = ops.fused_recurrent_gated_delta_rule(*args, initial_state=h0.to(DEV), output_final_state=True,
+                                                  use_qk_l2norm_in_kernel=True)
+    assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 5e-3 and rms_rel(s2.cpu(), s1.cpu()) < 5e-3
+
+
+def test_gdn_error_behaviour():
+    from infinitevl_amd import ops
+    z = torch.zeros(2, 4, 2, 128, dtype=torch.bfloat16, device=DEV)
+    v = torch.zeros(2, 4, 2, 256, dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros(2, 4, 2, device=DEV)
+    b = torch.zeros(2, 4, 2, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError, match="batch size is expected to be 1"):          # chunk.py:355-360
+        ops.chunk_gated_delta_rule(z, z, v, g, b, cu_seqlens=torch.tensor([0, 4, 8], device=DEV))
+    with pytest.raises(AssertionError):                                               # chunk.py:353
+        ops.chunk_gated_delta_rule(z, z, v, g, b[..., None])
+    with pytest.raises(ValueError):
+        ops.chunk_gated_delta_rule(z.float(), z.float(), v.float(), g, b)             # chunk.py:352 (fp32 refused)
+    with pytest.raises(ValueError):
+        ops.chunk_gated_delta_rule(z[..., :64], z[..., :64], v, g, b)                 # unsupported head shape
+
+
+# ---------------------------------------------------------------------------------------------
+# short conv / gated norm / gate math / rope
+# ---------------------------------------------------------------------------------------------
+def test_short_conv_golden_and_state_bit_exact():
+    from infinitevl_amd import ops
+    z = load_golden("short_conv")
+    D = z["weight"].shape[0]
+    conv = ops.ShortConvolution(D, 4).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        conv.weight.copy_(bf(z["weight"]))
+    y, cache = conv(bf(z["x"]).to(DEV), cache=None, output_final_state=True)
+    assert rms_rel(z["y"], y.float().cpu()) < 5e-3
+    assert torch.equal(bf(z["state"]), cache.cpu())                  # state = raw inputs: bit-exact
+    for i in range(5):
+        yi, cache2 = conv(bf(z["xs"][i]).to(DEV), cache=cache, output_final_state=True)
+        assert cache2.data_ptr() == cache.data_ptr()                 # updated in place (convolution.py:213)
+        assert rms_rel(z["ys"][i], yi.float().cpu()) < 5e-3
+        assert torch.equal(bf(z["states"][i]), cache.cpu())
+    y3, st3 = conv(bf(z["x3"]).to(DEV), cache=None, output_final_state=True)
+    assert rms_rel(z["y3"], y3.float().cpu()) < 5e-3 and torch.equal(bf(z["state3"]), st3.cpu())
+
+
+def test_short_conv_carry_in_split_invariance_full_width():
+    """D=8192 (q+k+v channels of InfiniteVL-3B), T=1024: one call == any split with the state carried,
+    bit for bit (the semantics streaming needs)."""
+    from infinitevl_amd import ops
+    torch.manual_seed(0)
+    D, T = 8192, 1024
+    conv = ops.ShortConvolution(D, 4).to(DEV, torch.bfloat16)
+    x = bf(torch.randn(2, T, D)).to(DEV)
+    y_full, s_full = conv(x, cache=None, output_final_state=True)
+    for cuts in ([256] * 4, [1, 2, 3, 1018], [1000, 24], [7] * 146 + [2]):
+        st, ys, pos = None, [], 0
+        for n in cuts:
+            yi, st = conv(x[:, pos:pos + n], cache=st, output_final_state=True)
+            ys.append(yi)
+            pos += n
+        assert torch.equal(torch.cat(ys, 1), y_full) and torch.equal(st, s_full), cuts[:3]
+    y_ref, _ = ogdn.short_conv(x[:1, :64].float().cpu(), conv.weight.float().cpu().reshape(D, 4), None)
+    assert rms_rel(y_ref, y_full[:1, :64].float().cpu()) < 5e-3
+
+
+def test_rmsnorm_gate_golden():
+    from infinitevl_amd import ops
+    z = load_golden("rmsnorm_gate")
+    n = ops.FusedRMSNormGated(256, eps=float(z["eps"])).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        n.weight.copy_(bf(z["weight"]))
+    y = n(bf(z["x"]).to(DEV), bf(z["gate"]).to(DEV))
+    assert rms_rel(z["y"], y.float().cpu()) < 5e-3
+
+
+def test_gate_math_vs_oracle():
+    from infinitevl_amd import ops
+    torch.manual_seed(2)
+    a, b = bf(torch.randn(2, 50, 16) * 4), bf(torch.randn(2, 50, 16) * 4)
+    a[0, 0, 0], a[0, 0, 1] = 30.0, -30.0                      # softplus threshold / underflow branches
+    A_log = torch.log(torch.empty(16).uniform_(0.5, 16))
+    dt = torch.randn(16) * 0.5
+    g, beta = ops.gdn_gate(a.to(DEV), b.to(DEV), A_log.to(DEV), dt.to(DEV))
+    g_ref, b_ref = ogdn.gate_math(a, b, A_log, dt)
+    assert g.dtype == torch.float32 and rms_rel(g_ref, g.cpu()) < 1e-6
+    assert torch.equal(b_ref, beta.cpu())                    # bf16 sigmoid: bit-exact
+
+
+def test_mrope_golden_and_bit_exact_vs_reference_arithmetic():
+    from infinitevl_amd import ops
+    z = load_golden("mrope")
+    # the fixture holds the reference's fp32 run; its bf16 arithmetic is reproduced bit for bit:
+    q, k = bf(z["q"]), bf(z["k"])                           # [B,H,T,d]
+    cos, sin = bf(z["cos"]), bf(z["sin"])
+    qe, ke = oswa.apply_mrope(q, k, cos, sin, z["mrope_section"].tolist())     # bf16 eager == std:982-983
+    qd, kd = q.transpose(1, 2).contiguous().to(DEV), k.transpose(1, 2).contiguous().to(DEV)
+    ops.apply_mrope_inplace(qd, kd, cos.to(DEV), sin.to(DEV), z["mrope_section"].tolist())
+    assert torch.equal(qe.transpose(1, 2).contiguous(), qd.cpu()) and torch.equal(ke.transpose(1, 2).contiguous(), kd.cpu())
+    assert rms_rel(z["q_out"].transpose(1, 2), qd.float().cpu()) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# sliding-window attention
+# ---------------------------------------------------------------------------------------------
+SWA_CASES = [
+    # B, T, Hq, Hkv, W, seen, via
+    (1, 5, 2, 1, 8, 0, "cat"), (2, 19, 4, 2, 8, 0, "cat"), (1, 6, 16, 2, 8, 9, "cat"), (1, 1, 16, 2, 8, 7, "cat"),
+    (1, 130, 16, 2, 4096, 0, "cat"), (1, 200, 2, 1, 96, 0, "cat"),
+    (1, 70, 2, 1, 96, 250, "ring"), (1, 256, 16, 2, 4096, 4500, "ring"), (1, 256, 16, 2, 4096, 1000, "ring"),
+    (1, 1, 16, 2, 4096, 5000, "ring"), (2, 1, 16, 2, 96, 40, "ring"), (1, 3, 16, 2, 96, 500, "ring"),
+    (1, 300, 2, 1, 96, 77, "ring"), (1, 64, 16, 2, 8192, 8191, "ring"), (1, 1, 16, 2, 2, 5, "ring"),
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv,W,seen,via", SWA_CASES)
+def test_swa_vs_oracle(B, T, Hq, Hkv, W, seen, via):
+    r = parity.swa_op_parity(DEV, B, T, Hq, Hkv, W, seen, seed=T + seen, via=via)
+    assert r["finite"] == 1.0 and r["o"] < 5e-3, r
+
+
+def _band_counts(n_prev, T, W):
+    """Decode WHICH keys each row attended: q = 0 makes the softmax uniform over the visible set, V holds
+    one-hot residues of the key index, so out[i, r] * n_vis(i) = #visible keys with residue r."""
+    lo, hi = oswa.window_bounds(n_prev, T, W)
+    S = n_prev + T
+    j = np.arange(S)
+    exp_lo = np.stack([np.bincount(j[lo[i]:hi[i] + 1] % 128, minlength=128) for i in range(T)])
+    exp_hi = np.stack([np.bincount((j[lo[i]:hi[i] + 1] // 128) % 128, minlength=128) for i in range(T)])
+    return lo, hi, exp_lo, exp_hi
+
+
+@pytest.mark.parametrize("W,seen,T", [(8, 0, 5), (8, 0, 19), (8, 7, 6), (8, 40, 1), (96, 250, 70), (4096, 0, 300),
+                                      (4096, 4000, 256), (4096, 9000, 256), (4096, 9000, 1), (4096, 4095, 64)])
+def test_swa_band_indices_bit_exact(W, seen, T):
+    """The integer contract: the set of keys each query row sees."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d = 16, 2, 128
+    n_prev = oswa.n_prev_keys(W, seen)
+    lo, hi, exp_lo, exp_hi = _band_counts(n_prev, T, W)
+    S = n_prev + T
+    q = torch.zeros(1, Hq, T, d, dtype=torch.bfloat16, device=DEV)
+    k = bf(torch.randn(1, Hkv, S, d)).to(DEV)
+    j = torch.arange(S)
+    for which, expect in (("lo", exp_lo), ("hi", exp_hi)):
+        idx = (j % 128) if which == "lo" else (j // 128) % 128
+        v = torch.nn.functional.one_hot(idx, 128).to(torch.bfloat16)[None, None].expand(1, Hkv, S, d).contiguous().to(DEV)
+        out, _ = ops.swa_attention_interface(None, q, k, v, None, scaling=d ** -0.5, sliding_window=W)
+        got = out.float().cpu()[0]                                  # [T, Hq, 128]
+        n_vis = torch.from_numpy(hi - lo + 1).float()[:, None, None]
+        counts = torch.round(got * n_vis).to(torch.int64)
+        for h in (0, 7, 15):
+            assert np.array_equal(counts[:, h].numpy(), expect), (which, h)
+
+
+def test_swa_ring_path_equals_concatenated_path_bit_exact():
+    """Full-size property (InfiniteVL-3B heads, W=4096, T=256): attention over (ring cache ++ new) ==
+    attention over the torch.cat'ed tensors, bit for bit; and the ring equals the reference tail."""
+    from infinitevl_amd import ops
+    B, T, Hq, Hkv, d, W = 1, 256, 16, 2, 128, 4096
+    C = W - 1
+    torch.manual_seed(3)
+    kc = torch.zeros(B, Hkv, C, d, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    pos_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+    hist_k, hist_v = [], []
+    for step in range(20):                                         # 5120 tokens: the ring wraps
+        kn, vn = bf(torch.randn(B, T, Hkv, d)).to(DEV), bf(torch.randn(B, T, Hkv, d)).to(DEV)
+        qn = bf(torch.randn(B, T, Hq, d)).to(DEV)
+        o_ring = ops.swa_forward(qn, kn, vn, window=W, scaling=d ** -0.5, k_cache=kc, v_cache=vc, pos_dev=pos_dev)
+        hist_k.append(kn)
+        hist_v.append(vn)
+        k_all, v_all = torch.cat(hist_k, 1), torch.cat(hist_v, 1)
+        n_prev = min(C, step * T)
+        o_cat = ops.swa_forward(qn, k_all[:, k_all.shape[1] - n_prev - T:], v_all[:, v_all.shape[1] - n_prev - T:],
+                                window=W, scaling=d ** -0.5)
+        assert torch.equal(o_ring, o_cat), step
+        ops.swa_cache_append(kn, vn, kc, vc, pos_dev=pos_dev)
+        ops.counter_add(pos_dev, T)
+    assert int(pos_dev.item()) == 20 * T
+    tail = torch.cat(hist_k, 1)[:, -C:]                            # chronological last W-1 keys
+    idx = (torch.arange(C, device=DEV) + (20 * T - C)) % C
+    assert torch.equal(kc.index_select(2, idx).transpose(1, 2), tail)
+
+
+# ---------------------------------------------------------------------------------------------
+# layers, harness (row H), hipGraph, clone, constant memory
+# ---------------------------------------------------------------------------------------------
+def test_layer_stack_vs_oracle():
+    r = parity.layer_parity(DEV, T_prefill=130, n_decode=3, window=96, seed=0)
+    for name in ("prefill", "stream", "decode0", "decode1", "decode2"):
+        assert r[name] < 1.5e-2, r
+    assert r["gdn_state"] < 1.5e-2 and r["swa_keys"] < 6e-3, r
+
+
+def _small_stack(window=96, seed=3):
+    from infinitevl_amd.harness import InfiniteVLTextStack
+    from oracle import model as omodel
+    hc, oc = parity.small_configs(window)
+    params = parity.bf16_params(omodel.random_params(oc, seed=seed, vocab=hc.vocab_size))
+    stack = InfiniteVLTextStack(hc)
+    parity.load_params(stack, params)
+    return stack.to(DEV, torch.bfloat16).eval(), hc, oc, params
+
+
+def test_hipgraph_step_is_bit_exact_with_eager_and_fixes_frozen_window():
+    """One captured graph serves every step (device-resident counters): outputs, state and counters equal
+    the eager run bit for bit over 8 replays that cross the window fill."""
+    from infinitevl_amd.harness import GraphedStep
+    stack, hc, _, _ = _small_stack(window=200)
+    T = 70
+    xs = [bf(torch.randn(1, T, hc.hidden_size) * 0.5).to(DEV) for _ in range(9)]
+    with torch.no_grad():
+        c1 = stack.allocate_inference_cache(1)
+        eager, pos = [], 0
+        for x in xs:
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :].expand(3, 1, T)
+            eager.append(stack(inputs_embeds=x, position_ids=pid, past_key_values=c1)[0].clone())
+            pos += T
+        c2 = stack.allocate_inference_cache(1)
+        pid = torch.arange(0, T, device=DEV)[None, None, :].expand(3, 1, T)
+        stack(inputs_embeds=xs[0], position_ids=pid, past_key_values=c2)
+        gs = GraphedStep(stack, c2, 1, T)
+        for i in range(1, 9):
+            h, _ = gs.step(xs[i])
+            assert torch.equal(eager[i], h), i
+    assert c2.layers[0].cumulative_length == c1.layers[0].cumulative_length == 9 * T
+    assert c2.layers[0].size == c1.layers[0].size == 199
+    assert int(c2.layers[0]._pos_dev.item()) == 9 * T
+    assert torch.equal(c1.layers[1].recurrent_state, c2.layers[1].recurrent_state)
+    assert torch.equal(c1.layers[0].keys, c2.layers[0].keys)
+
+
+def test_clone_branch_decode_then_resume_stream():
+    """demo:357-438: clone the stream cache, greedy-decode on the clone, then continue the stream on the
+    original as if nothing happened; greedy tokens equal the oracle's."""
+    from infinitevl_amd.harness import clone_inference_cache, greedy_decode
+    from oracle import model as omodel
+    stack, hc, oc, params = _small_stack(window=96)
+    embed = params["embed_tokens.weight"]
+    with torch.no_grad():
+        cache, ocache = stack.allocate_inference_cache(1), omodel.new_cache(oc, torch.bfloat16)
+        x = bf(torch.randn(1, 130, hc.hidden_size) * 0.5)
+        pid = torch.arange(130)[None, None, :].expand(3, 1, 130).contiguous()
+        _, logits = stack(inputs_embeds=x.to(DEV), position_ids=pid.to(DEV), past_key_values=cache)
+        h_ref = omodel.text_stack(params, x.float(), pid, oc, ocache, torch.bfloat16, torch.bfloat16)
+        ref_logits = h_ref[0, -1] @ embed.T
+        assert rms_rel(ref_logits, logits[0, -1].float().cpu()) < 2e-2
+        qa = clone_inference_cache(cache)
+        first = logits[:, -1].argmax(-1)
+        toks = greedy_decode(stack, qa, first, steps=4)
+        # oracle greedy on a cloned oracle cache, teacher-forced with OUR tokens to avoid argmax ties
+        oqa = omodel.clone_cache(ocache)
+        tok, pos = int(first), 130
+        for s_ in range(4):
+            hq = omodel.text_stack(params, embed[torch.tensor([[tok]])], torch.full((3, 1, 1), pos), oc, oqa,
+                                   torch.bfloat16, torch.bfloat16)
+            lg = hq[0, -1] @ embed.T
+            top2 = lg.topk(2).values
+            if float(top2[0] - top2[1]) > 0.05 * float(lg.std()):      # unambiguous argmax
+                assert int(lg.argmax()) == int(toks[0, s_]), s_
+            tok, pos = int(toks[0, s_]), pos + 1
+        assert qa.get_seq_length() == 134 and cache.get_seq_length() == 130
+        x2 = bf(torch.randn(1, 70, hc.hidden_size) * 0.5)
+        pid2 = torch.arange(130, 200)[None, None, :].expand(3, 1, 70).contiguous()
+        h2, _ = stack(inputs_embeds=x2.to(DEV), position_ids=pid2.to(DEV), past_key_values=cache)
+        h2_ref = omodel.text_stack(params, x2.float(), pid2, oc, ocache, torch.bfloat16, torch.bfloat16)
+        assert rms_rel(h2_ref, h2.float().cpu()) < 1.5e-2
+
+
+def test_constant_memory_over_a_long_stream():
+    """The cache is the long-context mechanism: allocated memory is flat once the
+    window is full, however many tokens stream through (here 80 x 256 = 20480 tokens, window 1024)."""
+    from infinitevl_amd.harness import GraphedStep
+    stack, hc, _, _ = _small_stack(window=1024)
+    with torch.no_grad():
+        cache = stack.allocate_inference_cache(1)
+        gs = GraphedStep(stack, cache, 1, 256, logits_to_keep=1)
+        x = bf(torch.randn(1, 256, hc.hidden_size) * 0.5).to(DEV)
+        for _ in range(8):
+            gs.step(x)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for _ in range(72):
+            gs.step(x)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() == base
+        assert cache.get_seq_length() == 80 * 256 and torch.isfinite(gs.hidden.float()).all()
