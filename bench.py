@@ -109,12 +109,13 @@ def kernel_timings(device, chunk, window):
     res["swa_decode"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=dec_bytes,
                              achieved=dec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
     # bandwidth-bound helpers at T=chunk
-    x8 = rn(B, T, 8192)
-    conv = ops.ShortConvolution(8192, 4).to(device, torch.bfloat16)
-    cst = rn(B, 8192, 4)
-    t = event_time_ms(lambda: conv(x8, cache=cst, output_final_state=True), 50, st)
-    res["short_conv(q+k+v channels)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=2.0 * T * 8192 * 2,
-                                             achieved=2.0 * T * 8192 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    t = 0.0
+    for D_ in (2048, 2048, 4096):                         # q, k, v convs of one GDN layer (3 launches)
+        xc, cst = rn(B, T, D_), rn(B, D_, 4)
+        conv = ops.ShortConvolution(D_, 4).to(device, torch.bfloat16)
+        t += event_time_ms(lambda: conv(xc, cache=cst, output_final_state=True), 50, st)
+    res["short_conv(q,k,v: 3 launches)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=2.0 * T * 8192 * 2,
+                                               achieved=2.0 * T * 8192 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
     norm = ops.FusedRMSNormGated(256).to(device, torch.bfloat16)
     xo, go = rn(B, T, H, V), rn(B, T, H, V)
     t = event_time_ms(lambda: norm(xo, go), 50, st)
@@ -131,7 +132,12 @@ def cpu_baseline(chunk, window):
     `chunk`-token step with a full window, extrapolated x9 to the 36-layer stack."""
     from oracle import model as omodel
     from oracle.cache import SwaCounters
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    # small-operator torch CPU code collapses when oversubscribed (72 s/step on 256 threads vs 0.5 s on 8)
+    torch.set_num_threads(max(1, min(ncores, 32)))
     oc = omodel.OracleConfig(sliding_window=window, layer_types=["sliding_attention"] + ["linear_attention"] * 3)
     params = omodel.random_params(oc, seed=0)
     cache = omodel.new_cache(oc)
@@ -149,7 +155,7 @@ def cpu_baseline(chunk, window):
         omodel.text_stack(params, x, pid, oc, cache)
         n += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or n >= 8:
+        if el > 12.0 or n >= 40:
             break
     per_period = el / n
     return dict(value=chunk / (per_period * 9.0), unit="tok/s", cores=torch.get_num_threads(), kind="port",
