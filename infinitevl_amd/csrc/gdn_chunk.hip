@@ -55,7 +55,7 @@ __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >
 // LDS map (bytes).  Row strides are padded so 16-byte fragment reads of 32 consecutive rows spread banks.
 constexpr int P_LDK = 136;                         // bf16 elements per row of kh/qh/kb/stage (272 B)
 constexpr int P_LDT = 72;                          // bf16 elements per row of kbT/vbT/TwB/TuB (144 B)
-constexpr int P_LDF = 65;                          // f32 elements per row of L / T
+constexpr int P_LDF = 68;                          // f32 elements per row of L / T (16-byte aligned rows)
 constexpr int P_LDY = 33;
 constexpr int P_KH = 0;
 constexpr int P_QH = P_KH + GC * P_LDK * 2;        // later: TwB (kh region later: TuB)
@@ -67,10 +67,7 @@ constexpr int P_T = P_L + GC * P_LDF * 4;
 constexpr int P_Y = P_T + GC * P_LDF * 4;
 constexpr int P_SM = P_Y + 32 * P_LDY * 4;         // gam[64], beta[64], eg[64]
 constexpr int P_BYTES = P_SM + 3 * GC * 4;
-constexpr int P_TWB = P_QH;                        // qh is dead after S2
-constexpr int P_TUB = P_KH;                        // kh is dead after S2
 static_assert(P_BYTES <= 160 * 1024, "pre-pass LDS budget");
-static_assert(GC * P_LDT * 2 <= GC * P_LDK * 2, "TwB / TuB must fit in the qh / kh regions");
 
 // fp32 16x16 tile product on v_mfma_f32_16x16x4_f32 from LDS operands: acc += A[a_r0.., a_c0..] * B[b_r0.., b_c0..]
 __device__ __forceinline__ f32x4 tile16_f32(f32x4 acc, const float* A, int lda, int a_r0, int a_c0,
@@ -92,7 +89,7 @@ __device__ __forceinline__ void store16_f32(float* Cm, int ldc, int r0, int c0, 
 __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const float* __restrict__ g, const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws,
-    int T, int H, int t_seg0, int nt_seg, int l2norm) {
+    int T, int H, int t_seg0, int nt_seg, int l2norm, int dbg_stop, long long* trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
@@ -105,10 +102,9 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   float* s_gam = (float*)(smem + P_SM);
   float* s_beta = s_gam + GC;
   float* s_eg = s_beta + GC;
-  bf16_t* s_twb = (bf16_t*)(smem + P_TWB);
-  bf16_t* s_tub = (bf16_t*)(smem + P_TUB);
   bf16_t* s_stage = (bf16_t*)(smem + P_KB);
 
+  trace_stamp(trace, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int ci = blockIdx.x;                  // chunk within the segment
@@ -118,13 +114,32 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   const int nvalid = min(GC, T - t0);
   unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * WS_STRIDE;
 
+  // ---- issue every global load of the chunk up front (clamped rows, zeroed later): 16 x 16 B per thread
+  //      in flight at once instead of one HBM round trip per conditional row ------------------------
+  const int oct = tid & 15, rg = tid >> 4;         // q,k: 16 column octets x 16 row groups of 4 rows
+  const int voct = tid & 31, vrg = tid >> 5;       // v  : 32 column octets x  8 row groups of 8 rows
+  u32x4 kraw[4], qraw[4], vraw[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(4 * rg + r, nvalid - 1);
+    const size_t tok = ((size_t)b * T + t0 + row) * H + h;
+    kraw[r] = *(const u32x4*)(k + tok * GK + 8 * oct);
+    qraw[r] = *(const u32x4*)(q + tok * GK + 8 * oct);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = min(8 * vrg + r, nvalid - 1);
+    const size_t tok = ((size_t)b * T + t0 + row) * H + h;
+    vraw[r] = *(const u32x4*)(v + tok * GV + 8 * voct);
+  }
   // ---- S0: g, beta; chunk-local inclusive cumsum (wave 0) -------------------------------------
   if (wave == 0) {
     float gv = 0.f, bv = 0.f;
-    if (lane < nvalid) {
-      const size_t tok = ((size_t)b * T + t0 + lane) * H + h;
-      gv = g[tok];
-      bv = bf2f(beta[tok]);
+    {
+      const size_t tok = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
+      const float g_ld = g[tok];
+      const float b_ld = bf2f(beta[tok]);
+      if (lane < nvalid) { gv = g_ld; bv = b_ld; }
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -144,24 +159,22 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   __syncthreads();
   const float gam_last = s_gam[nvalid - 1];
 
-  // ---- S1: load q,k (4 rows x 8 cols per thread), l2norm, bf16; kh,qh,kb row-major, kbT transposed,
-  //          Qh -> global, KdT -> global ------------------------------------------------------------
+  trace_stamp(trace, 1);
+  if (dbg_stop == 1) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
+  // ---- S1: l2norm, bf16; kh,qh,kb row-major, kbT transposed, Qh -> global, KdT -> global ---------
   {
-    const int oct = tid & 15, rg = tid >> 4;       // 16 column octets x 16 row groups of 4 rows
     float kf[4][8], qf[4][8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * rg + r;
-      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, qv = u32x4{0u, 0u, 0u, 0u};
-      if (row < nvalid) {
-        const size_t tok = ((size_t)b * T + t0 + row) * H + h;
-        kv = *(const u32x4*)(k + tok * GK + 8 * oct);
-        qv = *(const u32x4*)(q + tok * GK + 8 * oct);
-      }
+      const bool ok = row < nvalid;
+      const u32x4 kv = kraw[r], qv = qraw[r];
       kf[r][0] = bflo(kv.x); kf[r][1] = bfhi(kv.x); kf[r][2] = bflo(kv.y); kf[r][3] = bfhi(kv.y);
       kf[r][4] = bflo(kv.z); kf[r][5] = bfhi(kv.z); kf[r][6] = bflo(kv.w); kf[r][7] = bfhi(kv.w);
       qf[r][0] = bflo(qv.x); qf[r][1] = bfhi(qv.x); qf[r][2] = bflo(qv.y); qf[r][3] = bfhi(qv.y);
       qf[r][4] = bflo(qv.z); qf[r][5] = bfhi(qv.z); qf[r][6] = bflo(qv.w); qf[r][7] = bfhi(qv.w);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { kf[r][c] = ok ? kf[r][c] : 0.f; qf[r][c] = ok ? qf[r][c] : 0.f; }
       if (l2norm) {
         float ks = 0.f, qs = 0.f;
 #pragma unroll
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         kbv[r][c] = bf_round(kf[r][c] * bt);
-        kd[r][c] = row < nvalid ? kf[r][c] * dec : 0.f;
+        kd[r][c] = kf[r][c] * dec;              // padded rows: k = 0
       }
 #pragma unroll
       for (int c2 = 0; c2 < 4; ++c2) {
@@ -211,17 +224,12 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   }
   // ---- S1b: v (8 rows x 8 cols per thread) -> vbT = bf16(beta v)^T -----------------------------
   {
-    const int oct = tid & 31, rg = tid >> 5;       // 32 column octets x 8 row groups of 8 rows
     float vf[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int row = 8 * rg + r;
-      u32x4 vv = u32x4{0u, 0u, 0u, 0u};
-      if (row < nvalid) {
-        const size_t tok = ((size_t)b * T + t0 + row) * H + h;
-        vv = *(const u32x4*)(v + tok * GV + 8 * oct);
-      }
-      const float bt = s_beta[row];
+      const int row = 8 * vrg + r;
+      const u32x4 vv = vraw[r];
+      const float bt = s_beta[row];               // 0 for padded rows
       vf[r][0] = bflo(vv.x) * bt; vf[r][1] = bfhi(vv.x) * bt; vf[r][2] = bflo(vv.y) * bt; vf[r][3] = bfhi(vv.y) * bt;
       vf[r][4] = bflo(vv.z) * bt; vf[r][5] = bfhi(vv.z) * bt; vf[r][6] = bflo(vv.w) * bt; vf[r][7] = bfhi(vv.w) * bt;
     }
@@ -230,11 +238,13 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       u32x4 w;
       w.x = pack2bf(vf[0][c], vf[1][c]); w.y = pack2bf(vf[2][c], vf[3][c]);
       w.z = pack2bf(vf[4][c], vf[5][c]); w.w = pack2bf(vf[6][c], vf[7][c]);
-      *(u32x4*)(s_vbT + (8 * oct + c) * P_LDT + 8 * rg) = w;
+      *(u32x4*)(s_vbT + (8 * voct + c) * P_LDT + 8 * vrg) = w;
     }
   }
   __syncthreads();
 
+  trace_stamp(trace, 2);
+  if (dbg_stop == 2) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S2: L = tril(kb kh^T, -1) -> s_L (fp32);  Aqk = tril((qh kh^T) * Gamma) -> global bf16 ------
   //          wave w -> 32x32 tile (mi = w>>1, ni = w&1); tile (0,1) lies above the diagonal.
   {
@@ -276,6 +286,8 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   }
   __syncthreads();
 
+  trace_stamp(trace, 3);
+  if (dbg_stop == 3) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S3: T = (I + L)^-1 ----------------------------------------------------------------------
   // (a) diagonal 16x16 blocks by forward substitution: wave w -> block w, lane c<16 -> column c.
   if (lane < 16) {
@@ -324,16 +336,37 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   }
   __syncthreads();
 
-  // ---- S4: Tw, Tu = Tw * e^{gamma_i - gamma_j} -> bf16 (into the dead qh / kh regions) -----------
-  for (int idx = tid; idx < GC * GC; idx += 256) {
-    const int i = idx >> 6, j = idx & 63;
-    const float t = s_T[i * P_LDF + j];
-    s_twb[i * P_LDT + j] = f2bf(t);
-    s_tub[i * P_LDT + j] = f2bf(i >= j ? t * __expf(s_gam[i] - s_gam[j]) : 0.f);
+  trace_stamp(trace, 4);
+  if (dbg_stop == 4) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
+  trace_stamp(trace, 5);
+  if (dbg_stop == 5) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
+  // ---- S5: w = bf16(Tw) kb  (64x64 . 64x128): wave w -> columns 32w..32w+31, both row tiles.
+  //          A fragments are built straight from the fp32 T in LDS (rounded to bf16 in registers:
+  //          the reference stores Aw/Au in bf16, wy_fast.py:341-343). ------------------------------
+  u32x4 twf[2][4];          // bf16(Tw)[row 32mi + l31][16ks + 8hi .. +7]
+  u32x4 tuf[2][4];          // bf16(Tw * e^{gamma_i - gamma_j}) same positions (Tu)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int i = 32 * mi + l31;
+    const float gi = s_gam[i];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 t0 = *(const f32x4*)(s_T + i * P_LDF + 16 * ks + 8 * hi);
+      const f32x4 t1 = *(const f32x4*)(s_T + i * P_LDF + 16 * ks + 8 * hi + 4);
+      const f32x4 g0 = *(const f32x4*)(s_gam + 16 * ks + 8 * hi);
+      const f32x4 g1 = *(const f32x4*)(s_gam + 16 * ks + 8 * hi + 4);
+      float tw[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      float gj[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      float tu[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 16 * ks + 8 * hi + e;
+        tu[e] = i >= j ? tw[e] * __expf(gi - gj[e]) : 0.f;
+      }
+      twf[mi][ks] = u32x4{pack2bf(tw[0], tw[1]), pack2bf(tw[2], tw[3]), pack2bf(tw[4], tw[5]), pack2bf(tw[6], tw[7])};
+      tuf[mi][ks] = u32x4{pack2bf(tu[0], tu[1]), pack2bf(tu[2], tu[3]), pack2bf(tu[4], tu[5]), pack2bf(tu[6], tu[7])};
+    }
   }
-  __syncthreads();
-
-  // ---- S5: w = Tw kb  (64x64 . 64x128): wave w -> columns 32w..32w+31, both row tiles ------------
   {
     f32x16 acc[2];
 #pragma unroll
@@ -345,13 +378,10 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     for (int ks = 0; ks < GC / 16; ++ks) {
       const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const u32x4 afr = *(const u32x4*)(s_twb + (32 * mi + l31) * P_LDT + 8 * hi + 16 * ks);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr), mf(bfr), acc[mi], 0, 0, 0);
-      }
+      for (int mi = 0; mi < 2; ++mi)
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(twf[mi][ks]), mf(bfr), acc[mi], 0, 0, 0);
     }
     // Wg = bf16(bf16(w) * e^gamma_i) staged row-major in the (dead) kb region
-    __syncthreads();     // every wave is done reading s_kb (S2) long ago; kbT/twb are separate regions
     const int j = 32 * wave + l31;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -368,6 +398,8 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     *(u32x4*)(rec + WS_WG + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_stage + row * P_LDK + 8 * ch);
   }
 
+  trace_stamp(trace, 6);
+  if (dbg_stop == 6) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S6: u = Tu vb  (64x64 . 64x256): wave w -> columns 64w..64w+63 ; UT[col][time] to global --
   {
 #pragma unroll
@@ -383,10 +415,8 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       for (int ks = 0; ks < GC / 16; ++ks) {
         const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const u32x4 afr = *(const u32x4*)(s_tub + (32 * mi + l31) * P_LDT + 8 * hi + 16 * ks);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr), mf(bfr), acc[mi], 0, 0, 0);
-        }
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(tuf[mi][ks]), mf(bfr), acc[mi], 0, 0, 0);
       }
       bf16_t* ut = (bf16_t*)(rec + WS_UT) + (size_t)col * GC;
 #pragma unroll
@@ -400,6 +430,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
         }
     }
   }
+  trace_stamp(trace, 7);
 }
 
 // ==================================================================================================
@@ -411,10 +442,11 @@ constexpr int S_LDV = 72;      // bf16 per row of v_new^T [32 cols][64 t] (144 B
 __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
     const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
-    int T, int H, int t_seg0, int nt_seg, float scale) {
+    int T, int H, int t_seg0, int nt_seg, float scale, long long* trace) {
   __shared__ __attribute__((aligned(16))) bf16_t s_st[G_BV * S_LDS];
   __shared__ __attribute__((aligned(16))) bf16_t s_vn[G_BV * S_LDV];
 
+  trace_stamp(trace, 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int v0 = blockIdx.x * G_BV;
@@ -423,53 +455,67 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
   const bool is_p = wave < 2;                 // waves 0,1: v_new rows 32*wave.. ; waves 2,3: output rows 32*(wave-2)..
   const int mrow0 = 32 * (wave & 1);
 
-  // state slab rows 32*wave + crow32(r,hi), column v0 + l31
-  f32x16 S;
-  {
-    const size_t base = ((size_t)bh * GK + 32 * wave) * GV + v0 + l31;
-    if (h0 != nullptr) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = load_state(h0, base + (size_t)crow32(r, hi) * GV, h0_dtype);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
-    }
-  }
-
-  for (int ci = 0; ci < nt_seg; ++ci) {
+  // operand fragments of one chunk (global, L2/MALL-resident; independent of the state) -------------
+  struct Frags {
+    u32x4 afr[8];      // Wg (waves 0,1) or Qh (waves 2,3): rows mrow0 + l31, k = 16ks + 8hi..
+    u32x4 kdfr[4];     // KdT rows 32*wave + l31 (state rows of this wave), k = time
+    u32x4 aqfr[4];     // Aqk rows mrow0 + l31 (waves 2,3)
+    u32x2 ufr[4];      // UT[v0 + l31][mrow0 + 8 r4 + 4 hi + 0..3] (waves 0,1)
+    f32x4 egv[4];      // e^gamma for rows mrow0 + 8 r4 + 4 hi + 0..3 (waves 2,3)
+    float egl;
+  };
+  auto load_frags = [&](Frags& f, int ci) {
     const unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * WS_STRIDE;
-    const int tc0 = t_seg0 + ci * GC;
-
-    // ---- operand fragments of this chunk (global, L2-resident; independent of the state) --------
-    u32x4 afr[8];                                   // Wg (waves 0,1) or Qh (waves 2,3): rows mrow0 + l31
-    {
-      const bf16_t* ap = (const bf16_t*)(rec + (is_p ? WS_WG : WS_QH)) + (size_t)(mrow0 + l31) * GK + 8 * hi;
+    const bf16_t* ap = (const bf16_t*)(rec + (is_p ? WS_WG : WS_QH)) + (size_t)(mrow0 + l31) * GK + 8 * hi;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) afr[ks] = *(const u32x4*)(ap + 16 * ks);
-    }
-    u32x4 kdfr[4];                                  // KdT rows 32*wave + l31 (state rows of this wave)
-    {
-      const bf16_t* kp = (const bf16_t*)(rec + WS_KDT) + (size_t)(32 * wave + l31) * GC + 8 * hi;
+    for (int ks = 0; ks < 8; ++ks) f.afr[ks] = *(const u32x4*)(ap + 16 * ks);
+    const bf16_t* kp = (const bf16_t*)(rec + WS_KDT) + (size_t)(32 * wave + l31) * GC + 8 * hi;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kdfr[ks] = *(const u32x4*)(kp + 16 * ks);
-    }
-    u32x4 aqfr[4];                                  // Aqk rows mrow0 + l31 (waves 2,3)
-    u32x2 ufr[4];                                   // UT[v0 + l31][mrow0 + 8 r4 + 4 hi + 0..3] (waves 0,1)
-    f32x4 egv[4];                                   // e^gamma for rows mrow0 + 8 r4 + 4 hi + 0..3 (waves 2,3)
+    for (int ks = 0; ks < 4; ++ks) f.kdfr[ks] = *(const u32x4*)(kp + 16 * ks);
     if (is_p) {
       const bf16_t* up = (const bf16_t*)(rec + WS_UT) + (size_t)(v0 + l31) * GC + mrow0 + 4 * hi;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) ufr[r4] = *(const u32x2*)(up + 8 * r4);
+      for (int r4 = 0; r4 < 4; ++r4) f.ufr[r4] = *(const u32x2*)(up + 8 * r4);
     } else {
       const bf16_t* qp = (const bf16_t*)(rec + WS_AQK) + (size_t)(mrow0 + l31) * GC + 8 * hi;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) aqfr[ks] = *(const u32x4*)(qp + 16 * ks);
+      for (int ks = 0; ks < 4; ++ks) f.aqfr[ks] = *(const u32x4*)(qp + 16 * ks);
       const float* ep = (const float*)(rec + WS_EG) + mrow0 + 4 * hi;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) egv[r4] = *(const f32x4*)(ep + 8 * r4);
+      for (int r4 = 0; r4 < 4; ++r4) f.egv[r4] = *(const f32x4*)(ep + 8 * r4);
     }
-    const float egl = *(const float*)(rec + WS_EGL);
+    f.egl = *(const float*)(rec + WS_EGL);
+  };
 
+  trace_stamp(trace, 17);
+  Frags fa, fb;
+  load_frags(fa, 0);          // first chunk's operands and the state slab are fetched concurrently
+
+  // state slab rows 32*wave + crow32(r,hi), column v0 + l31 (dtype branch hoisted: 16 loads in flight)
+  f32x16 S;
+  {
+    const size_t base = ((size_t)bh * GK + 32 * wave) * GV + v0 + l31;
+    if (h0 == nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    } else if (h0_dtype == IVL_F32) {
+      const float* hp = (const float*)h0 + base;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = hp[(size_t)crow32(r, hi) * GV];
+    } else {
+      const bf16_t* hp = (const bf16_t*)h0 + base;
+      bf16_t raw[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) raw[r] = hp[(size_t)crow32(r, hi) * GV];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = bf2f(raw[r]);
+    }
+  }
+
+  // one chunk of the recurrence with the operands in `f` ---------------------------------------------
+  auto chunk_step = [&](const Frags& f, int ci) {
+    const int tc0 = t_seg0 + ci * GC;
+    if (ci < 4) trace_stamp(trace, 18 + 4 * ci);
     // ---- (i) publish the state slab as bf16 S^T[col][k] -----------------------------------------
     __syncthreads();          // previous chunk's readers of s_st / s_vn are done
 #pragma unroll
@@ -480,24 +526,30 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       *(u32x2*)(s_st + l31 * S_LDS + 32 * wave + 8 * r4 + 4 * hi) = w;
     }
     __syncthreads();
+    if (ci < 4) trace_stamp(trace, 19 + 4 * ci);
 
-    // ---- (ii) [Wg ; Qh] S : every wave one 32x32 tile over K = 128 --------------------------------
-    f32x16 acc;
+    // ---- (ii) [Wg ; Qh] S : every wave one 32x32 tile over K = 128 (two independent accumulation
+    //           chains so consecutive MFMAs do not wait on each other) -------------------------------
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     {
       const bf16_t* bp = s_st + l31 * S_LDS + 8 * hi;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const u32x4 bfr = *(const u32x4*)(bp + 16 * ks);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(afr[ks]), mf(bfr), acc, 0, 0, 0);
+      for (int ks = 0; ks < 8; ks += 2) {
+        const u32x4 b0 = *(const u32x4*)(bp + 16 * ks);
+        const u32x4 b1 = *(const u32x4*)(bp + 16 * ks + 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(f.afr[ks]), mf(b0), acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(f.afr[ks + 1]), mf(b1), acc2, 0, 0, 0);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     }
     if (is_p) {
       // v_new = u - Wg S  -> bf16 -> v_new^T[col][time]
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float u0 = bflo(ufr[r4].x), u1 = bfhi(ufr[r4].x), u2 = bflo(ufr[r4].y), u3 = bfhi(ufr[r4].y);
+        const float u0 = bflo(f.ufr[r4].x), u1 = bfhi(f.ufr[r4].x), u2 = bflo(f.ufr[r4].y), u3 = bfhi(f.ufr[r4].y);
         u32x2 w;
         w.x = pack2bf(u0 - acc[4 * r4 + 0], u1 - acc[4 * r4 + 1]);
         w.y = pack2bf(u2 - acc[4 * r4 + 2], u3 - acc[4 * r4 + 3]);
@@ -508,31 +560,45 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * r4 + i] *= egv[r4][i];
+        for (int i = 0; i < 4; ++i) acc[4 * r4 + i] *= f.egv[r4][i];
     }
     __syncthreads();
+    if (ci < 4) trace_stamp(trace, 20 + 4 * ci);
 
     // ---- (iii) output rows (waves 2,3): + Aqk v_new ; state update (all waves) ----------------------
     const bf16_t* vp = s_vn + l31 * S_LDV + 8 * hi;
     u32x4 vfr[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) vfr[ks] = *(const u32x4*)(vp + 16 * ks);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] *= f.egl;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(f.kdfr[ks]), mf(vfr[ks]), S, 0, 0, 0);
     if (!is_p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(aqfr[ks]), mf(vfr[ks]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(f.aqfr[ks]), mf(vfr[ks]), acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = tc0 + mrow0 + crow32(r, hi);
         if (t < T) o[(((size_t)b * T + t) * H + h) * GV + v0 + l31] = f2bf(acc[r] * scale);
       }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] *= egl;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(kdfr[ks]), mf(vfr[ks]), S, 0, 0, 0);
+    if (ci < 4) trace_stamp(trace, 21 + 4 * ci);
+  };
+
+  // software pipeline, unrolled by two so the two fragment sets stay in fixed registers: the loads of
+  // chunk c+1 are issued before chunk c is computed and are only waited for when chunk c+1 starts.
+  for (int ci = 0; ci < nt_seg; ci += 2) {
+    if (ci + 1 < nt_seg) load_frags(fb, ci + 1);
+    chunk_step(fa, ci);
+    if (ci + 1 < nt_seg) {
+      if (ci + 2 < nt_seg) load_frags(fa, ci + 2);
+      chunk_step(fb, ci + 1);
+    }
   }
+  trace_stamp(trace, 34);
 
   if (ht != nullptr) {
     const size_t base = ((size_t)bh * GK + 32 * wave) * GV + v0 + l31;
@@ -573,6 +639,16 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_BYTES);
     attr_set = true;
   }
+  static int dbg_stop = -1;
+  if (dbg_stop < 0) {
+    const char* e = getenv("IVL_DEBUG_PREP_STOP");
+    dbg_stop = e ? atoi(e) : 0;
+  }
+  static int dbg_skip_scan = -1;
+  if (dbg_skip_scan < 0) {
+    const char* e = getenv("IVL_DEBUG_SKIP_SCAN");
+    dbg_skip_scan = e ? atoi(e) : 0;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int NT = (T + GC - 1) / GC;
   const int segc = seg_chunks(NT);
@@ -583,15 +659,16 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     const bool first = c0 == 0, last = c0 + nseg >= NT;
     hipLaunchKernelGGL(gdn_chunk_prepare_kernel, dim3(nseg, B * H), dim3(256), P_BYTES, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb,
-                       T, H, c0 * GC, nseg, use_qk_l2norm);
+                       T, H, c0 * GC, nseg, use_qk_l2norm, dbg_stop, debug_trace_buffer());
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
     if (rc != IVL_OK) return rc;
     const void* hin = first ? h0 : (const void*)carry;
     const int hin_dt = first ? h0_dtype : IVL_F32;
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
+    if (dbg_skip_scan) continue;
     hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(GV / G_BV, B * H), dim3(256), 0, st,
-                       (const unsigned char*)wsb, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
+                       (const unsigned char*)wsb, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale, debug_trace_buffer());
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
   }

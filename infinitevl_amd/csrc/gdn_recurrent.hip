@@ -37,9 +37,17 @@ __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
   float S[16];
   {
     const size_t base = ((size_t)bh * REC_K + row0) * V + v0 + c;
-    if (h0 != nullptr) {
+    if (h0 != nullptr && h0_dtype == IVL_F32) {          // dtype branch hoisted: 16 loads in flight
+      const float* hp = (const float*)h0 + base;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = load_state(h0, base + (size_t)r * V, h0_dtype);
+      for (int r = 0; r < 16; ++r) S[r] = hp[(size_t)r * V];
+    } else if (h0 != nullptr) {
+      const bf16_t* hp = (const bf16_t*)h0 + base;
+      bf16_t raw[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) raw[r] = hp[(size_t)r * V];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = bf2f(raw[r]);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
@@ -114,8 +122,15 @@ __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
   }
   if (ht != nullptr) {
     const size_t base = ((size_t)bh * REC_K + row0) * V + v0 + c;
+    if (ht_dtype == IVL_F32) {
+      float* hp = (float*)ht + base;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) store_state(ht, base + (size_t)r * V, ht_dtype, S[r]);
+      for (int r = 0; r < 16; ++r) hp[(size_t)r * V] = S[r];
+    } else {
+      bf16_t* hp = (bf16_t*)ht + base;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hp[(size_t)r * V] = f2bf(S[r]);
+    }
   }
 }
 

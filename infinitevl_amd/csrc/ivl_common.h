@@ -56,6 +56,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// ---- optional in-kernel timeline (debug): block (0,0,0), thread 0 stamps the shader clock ------
+// The buffer is set with ivl_debug_set_trace(); NULL (the default) compiles to one scalar branch.
+__device__ __forceinline__ void trace_stamp(long long* trace, int slot) {
+  if (trace != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    trace[slot] = (long long)__builtin_readcyclecounter();
+}
+long long* debug_trace_buffer();
+
 // ---- host side -------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

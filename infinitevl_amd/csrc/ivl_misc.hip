@@ -16,6 +16,9 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static long long* g_trace = nullptr;
+long long* debug_trace_buffer() { return g_trace; }
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -263,6 +266,9 @@ static inline int grid_for(long long work_items, int block = 256, int cap = 256 
 using namespace ivl;
 
 extern "C" int ivl_abi_version(void) { return IVL_ABI_VERSION; }
+// Debug only (not part of the drop-in boundary): device buffer of >= 64 int64 slots that instrumented
+// kernels stamp with the shader clock at phase boundaries; NULL switches the timeline off.
+extern "C" void ivl_debug_set_trace(void* device_buffer) { ivl::g_trace = (long long*)device_buffer; }
 extern "C" const char* ivl_last_error(void) { return g_err; }
 
 extern "C" int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,

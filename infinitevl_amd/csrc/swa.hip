@@ -101,26 +101,25 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
   const int srow = tid >> 4, schunk = tid & 15;
   u32x4 kreg[4], vreg[4];
   auto load_tile = [&](int kt) {
+    // branch-free: every row issues its two 16-byte loads (clamped address), invalid rows are zeroed
+    // afterwards -- a conditional load per row would serialise one memory round trip per row.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = srow + 16 * i;
       const int j = kt * SWA_KT + r;
-      if (j < S) {
-        const bf16_t *kp, *vp;
-        if (j < n_ring) {
-          int slot = s0 + j;
-          if (slot >= p.C) slot -= p.C;
-          const long long off = (((long long)b * p.Hkv + hk) * p.C + slot) * SWA_D + schunk * 8;
-          kp = p.k_cache + off;
-          vp = p.v_cache + off;
-        } else {
-          const long long off = (long long)b * p.kn_sb + (long long)(j - n_ring) * p.kn_st + (long long)hk * p.kn_sh + schunk * 8;
-          kp = p.k_new + off;
-          vp = p.v_new + off;
-        }
-        kreg[i] = *(const u32x4*)kp;
-        vreg[i] = *(const u32x4*)vp;
-      } else {
+      const bool ok = j < S;
+      const int jc = ok ? j : S - 1;
+      const bool in_ring = jc < n_ring;
+      int slot = s0 + jc;
+      if (slot >= p.C) slot -= p.C;
+      const long long off_ring = (((long long)b * p.Hkv + hk) * p.C + (in_ring ? slot : 0)) * SWA_D + schunk * 8;
+      const long long off_new = (long long)b * p.kn_sb + (long long)(in_ring ? 0 : jc - n_ring) * p.kn_st +
+                                (long long)hk * p.kn_sh + schunk * 8;
+      const bf16_t* kp = in_ring ? p.k_cache + off_ring : p.k_new + off_new;
+      const bf16_t* vp = in_ring ? p.v_cache + off_ring : p.v_new + off_new;
+      kreg[i] = *(const u32x4*)kp;
+      vreg[i] = *(const u32x4*)vp;
+      if (!ok) {
         kreg[i] = u32x4{0u, 0u, 0u, 0u};
         vreg[i] = u32x4{0u, 0u, 0u, 0u};
       }
