@@ -48,16 +48,27 @@ def parse():
 
 
 def event_time_ms(fn, iters, stream):
-    """Average duration of `fn` (which launches on `stream`) measured with HIP events on that stream."""
+    """Average GPU duration of `fn`: `iters` calls are captured into one hipGraph (so the measurement is
+    not bound by the Python/ctypes launch overhead of ~10-30 us per call) and the replay is timed with HIP
+    events recorded on the stream the kernels run on."""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    cur = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        fn()
-    e1.record(stream)
+    reps = 5
+    e0.record(cur)
+    for _ in range(reps):
+        graph.replay()
+    e1.record(cur)
     e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / (iters * reps)
 
 
 def kernel_timings(device, chunk, window):
@@ -75,7 +86,7 @@ def kernel_timings(device, chunk, window):
     res = {}
 
     t = event_time_ms(lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state,
-                                                         use_qk_l2norm_in_kernel=True, final_state_out=state), 50, st)
+                                                         use_qk_l2norm_in_kernel=True, final_state_out=state), 20, st)
     gdn_bytes = 24672.0 * T + 2 * H * K * V * 4          # per-token bytes + fp32 state r+w per call
     res["gdn_chunk(prepare+scan)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=gdn_bytes,
                                           achieved=gdn_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")

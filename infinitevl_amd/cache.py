@@ -275,6 +275,17 @@ class StaticLinearLayerPrealloc(_HFLayer):
         self.start = True
         self.seq_len += int(T)
 
+    def ensure_started(self) -> None:
+        """Make the pre-allocated tensors equal to what the reference's first call uses (zero history,
+        std:298-300) and flip `start`: afterwards a captured hipGraph, which always reads the cache tensors,
+        computes the same thing as the eager first call that ignores them."""
+        if not self.start:
+            for n in ("conv_state_q", "conv_state_k", "conv_state_v", "recurrent_state"):
+                t = getattr(self, n)
+                if t is not None:
+                    t.zero_()
+            self.start = True
+
     def get_mask_sizes(self, cache_position: torch.Tensor) -> Tuple[int, int]:
         qlen = cache_position.shape[0] if cache_position is not None else 0
         return self.get_seq_length() + qlen, 0
@@ -371,6 +382,11 @@ class StaticCachePrealloc(_HFCache):
     def reset(self) -> None:
         for layer in self.layers:
             layer.reset()
+
+    def ensure_started(self) -> None:
+        for layer in self.layers:
+            if hasattr(layer, "ensure_started"):
+                layer.ensure_started()
 
     def clone(self) -> "StaticCachePrealloc":
         new = copy.copy(self)

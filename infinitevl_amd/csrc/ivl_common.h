@@ -19,17 +19,20 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned int)x) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
+// fp32 -> bf16, round-to-nearest-even, through the native __bf16 type: hipcc lowers the casts to the
+// gfx950 hardware conversion (v_cvt_pk_bf16_f32, two elements per instruction).  A hand-rolled integer
+// rounding with a NaN test costs ~10 VALU + a branch per element and made whole kernels
+// instruction-bound (gdn_chunk_prepare S1: 26k of 64k cycles).
+typedef __bf16 bf16_native2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  const bf16_native2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, v);
 }
 __device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
-}
 __device__ __forceinline__ float bflo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -203,6 +203,7 @@ class GraphedStep:
     def capture(self) -> None:
         """Warm up on a side stream with a throw-away clone of the cache state (demo:285-315), then
         capture.  The live cache is restored afterwards, so capture has no side effects on it."""
+        self.cache.ensure_started()          # a replayed graph always reads the cache tensors
         saved = self.cache.clone()
         saved_pos = self.position_ids.clone()
         s = torch.cuda.Stream()
@@ -249,6 +250,7 @@ class GraphedDecode:
         return lg
 
     def capture(self) -> None:
+        self.cache.ensure_started()
         saved, saved_pos, saved_tok = self.cache.clone(), self.position_ids.clone(), self.token.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
