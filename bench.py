@@ -119,19 +119,27 @@ def kernel_timings(device, chunk, window):
     dec_bytes = 1024.0 * window                           # 1024*min(p+1,W) B/token/layer
     res["swa_decode"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=dec_bytes,
                              achieved=dec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    # bandwidth-bound helpers at T=chunk
-    t = 0.0
-    for D_ in (2048, 2048, 4096):                         # q, k, v convs of one GDN layer (3 launches)
-        xc, cst = rn(B, T, D_), rn(B, D_, 4)
-        conv = ops.ShortConvolution(D_, 4).to(device, torch.bfloat16)
-        t += event_time_ms(lambda: conv(xc, cache=cst, output_final_state=True), 50, st)
-    res["short_conv(q,k,v: 3 launches)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=2.0 * T * 8192 * 2,
-                                               achieved=2.0 * T * 8192 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    norm = ops.FusedRMSNormGated(256).to(device, torch.bfloat16)
-    xo, go = rn(B, T, H, V), rn(B, T, H, V)
-    t = event_time_ms(lambda: norm(xo, go), 50, st)
+    # fused prologue (3 convs + gate math from one projection buffer) and gated norm at T=chunk
+    Dq, Dk, Dv = H * K, H * K, H * V
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+    ld = cols[4] + H
+    proj = rn(B, T, ld)
+    cw = [rn(D_, 1, 4) for D_ in (Dq, Dk, Dv)]
+    cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.randn(H, device=device, generator=g_), torch.randn(H, device=device, generator=g_)
+    t = event_time_ms(lambda: ops.gdn_prologue(proj, cols, cw, cs, cs, A32, dt32, H, Dq, Dk, Dv), 50, st)
+    pro_bytes = 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2)
+    res["gdn_prologue(3 convs + gates)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=pro_bytes,
+                                               achieved=pro_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    xo = rn(B, T, H, V)
+    wn = rn(V)
+    t = event_time_ms(lambda: ops.rmsnorm_swish_gate_strided(xo, proj[..., Dq + Dk + Dv:], ld, wn, 1e-5), 50, st)
     res["rmsnorm_swish_gate"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=3.0 * T * H * V * 2,
                                      achieved=3.0 * T * H * V * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    xh, rh, wh = rn(B, T, 2048), rn(B, T, 2048), rn(2048)
+    t = event_time_ms(lambda: ops.add_rmsnorm(xh, rh, wh, 1e-6), 50, st)
+    res["add_rmsnorm(decoder layer)"] = dict(ms=t, launches_per_step=72, bound="hbm", alg_bytes=4.0 * T * 2048 * 2,
+                                            achieved=4.0 * T * 2048 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
     for r in res.values():
         r["frac"] = r["achieved"] / r["peak"]
     return res
@@ -193,6 +201,7 @@ def main():
         torch.set_default_dtype(torch.float32)
     model = model.to(torch.bfloat16).eval()
     model.init_weights_(seed=0)
+    model.fuse_()                                  # fused projections + prologue/epilogue kernels
     B_local = 1                                    # one sequence per GPU (weak scaling over the batch)
     cache = model.allocate_inference_cache(B_local)
     T = args.chunk

@@ -160,6 +160,43 @@ int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, in
 /* *counter += delta on the device (graph-replayable position bookkeeping). */
 int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused prologue / epilogue entry points: the same arithmetic as the
+ * single-purpose entry points above, but reading the column blocks of ONE fused projection output
+ * (row stride `ld` elements) so that a Gated DeltaNet layer needs one projection GEMM and one
+ * prologue launch instead of six GEMMs + 3 conv + gate launches (call sites std:1261-1294).
+ * ------------------------------------------------------------------------------------------- */
+
+/* 3 short convs (+SiLU, carry-in, state in/out as in ivl_short_conv_fwd) + gate math (ivl_gdn_gate_fwd).
+ * proj bf16 [B*T, ld]; q|k|v|a|b start at columns col_*; outputs q [B,T,Dq], k [B,T,Dk], v [B,T,Dv] bf16
+ * contiguous, g fp32 [B,T,H], beta bf16 [B,T,H]. */
+int ivl_gdn_prologue_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
+                         const void* w_q, const void* w_k, const void* w_v,
+                         const void* sq_in, const void* sk_in, const void* sv_in,
+                         void* sq_out, void* sk_out, void* sv_out,
+                         const float* A_log, const float* dt_bias,
+                         void* q, void* k, void* v, float* g, void* beta,
+                         int B, int T, int H, int Dq, int Dk, int Dv, int W, int apply_silu, void* stream);
+
+/* ivl_rmsnorm_swish_gate_fwd with the gate read in place: gate element (token, head, c) at
+ * gate + token*gate_ld + head*N + c; x,y [rows = tokens*H, N] contiguous. */
+int ivl_rmsnorm_swish_gate_strided_fwd(const void* x, const void* gate, int64_t gate_ld, int H,
+                                       const void* weight, void* y, int rows, int N, float eps, void* stream);
+
+/* ivl_mrope_fwd on column blocks of a fused qkv projection: q element (b,t,h,c) at
+ * q + (b*T+t)*q_ld + h*d + c, k likewise with k_ld. */
+int ivl_mrope_strided_fwd(void* q, void* k, int64_t q_ld, int64_t k_ld, const void* cos, const void* sin,
+                          int B, int T, int Hq, int Hkv, int d, int s0, int s1, int s2, void* stream);
+
+/* Decoder-layer norm (std:1400-1420 / Qwen2RMSNorm) fused with the residual add:
+ *   h = bf16(x + residual) -> h_out   (skipped when residual == NULL: h = x)
+ *   y = bf16(weight * bf16(h * rsqrt(mean(h^2) + eps)));  x,residual,y,h_out bf16 [rows,N], N%8==0, N<=8192. */
+int ivl_add_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void* y, void* h_out,
+                        int rows, int N, float eps, void* stream);
+
+/* SwiGLU gate over a fused gate|up projection: y[r,i] = bf16(bf16(silu(gu[r,i])) * gu[r,I+i]) (std:945). */
+int ivl_silu_mul_fwd(const void* gate_up, void* y, int64_t rows, int I, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

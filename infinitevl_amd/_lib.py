@@ -21,6 +21,8 @@ EXPORTED_SYMBOLS = (
     "ivl_gdn_recurrent_fwd", "ivl_gdn_chunk_workspace_bytes", "ivl_gdn_chunk_fwd", "ivl_gdn_gate_fwd",
     "ivl_short_conv_fwd", "ivl_rmsnorm_swish_gate_fwd", "ivl_mrope_fwd",
     "ivl_swa_workspace_bytes", "ivl_swa_fwd", "ivl_swa_cache_append", "ivl_counter_add",
+    "ivl_gdn_prologue_fwd", "ivl_rmsnorm_swish_gate_strided_fwd", "ivl_mrope_strided_fwd",
+    "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd",
 )
 
 
@@ -85,6 +87,17 @@ def load() -> ctypes.CDLL:
     lib.ivl_swa_cache_append.argtypes = [vp, vp, i64, i64, i64, vp, vp, i, i, i, i, i, i64, vp, vp]
     lib.ivl_counter_add.restype = i
     lib.ivl_counter_add.argtypes = [vp, i64, vp]
+    lib.ivl_gdn_prologue_fwd.restype = i
+    lib.ivl_gdn_prologue_fwd.argtypes = [vp, i64, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
+    lib.ivl_rmsnorm_swish_gate_strided_fwd.restype = i
+    lib.ivl_rmsnorm_swish_gate_strided_fwd.argtypes = [vp, vp, i64, i, vp, vp, i, i, f, vp]
+    lib.ivl_mrope_strided_fwd.restype = i
+    lib.ivl_mrope_strided_fwd.argtypes = [vp, vp, i64, i64, vp, vp, i, i, i, i, i, i, i, i, vp]
+    lib.ivl_add_rmsnorm_fwd.restype = i
+    lib.ivl_add_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, f, vp]
+    lib.ivl_silu_mul_fwd.restype = i
+    lib.ivl_silu_mul_fwd.argtypes = [vp, vp, i64, i, vp]
     _lib = lib
     return lib
 

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .cache import StaticCachePrealloc
 from .modules import GatedDeltaNet, InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
 
@@ -68,10 +69,20 @@ class InfiniteVLRMSNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and x.dtype == torch.bfloat16:          # one launch instead of seven elementwise kernels
+            return ops.add_rmsnorm(x, None, self.weight, self.variance_epsilon)[0]
         dt = x.dtype
         xf = x.to(torch.float32)
         xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
         return self.weight * xf.to(dt)
+
+    def add_and_norm(self, x: torch.Tensor, residual: torch.Tensor):
+        """(x + residual, norm(x + residual)) in one launch."""
+        if x.is_cuda and x.dtype == torch.bfloat16:
+            y, h = ops.add_rmsnorm(x, residual, self.weight, self.variance_epsilon)
+            return h, y
+        h = residual + x
+        return h, self.forward(h)
 
 
 class InfiniteVLTextMLP(nn.Module):
@@ -81,7 +92,21 @@ class InfiniteVLTextMLP(nn.Module):
         self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
         self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
 
+        self._fused_w = None
+
+    @torch.no_grad()
+    def fuse_(self) -> "InfiniteVLTextMLP":
+        """gate|up projection weights in one tensor (one GEMM), parameters re-pointed at views of it."""
+        g, u = self.gate_proj.weight, self.up_proj.weight
+        self._fused_w = torch.cat([g.data, u.data], dim=0).contiguous()
+        n = g.shape[0]
+        g.data, u.data = self._fused_w[:n], self._fused_w[n:]
+        return self
+
     def forward(self, x):
+        if (self._fused_w is not None and x.is_cuda and x.dtype == torch.bfloat16
+                and self.gate_proj.weight.data_ptr() == self._fused_w.data_ptr()):
+            return self.down_proj(ops.silu_mul(F.linear(x, self._fused_w)))
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
@@ -107,10 +132,8 @@ class InfiniteVLDecoderLayer(nn.Module):
                               past_key_values=past_key_values, output_attentions=output_attentions,
                               use_cache=use_cache, cache_position=cache_position,
                               position_embeddings=position_embeddings, **kwargs)
-        hidden_states = residual + h
-        residual = hidden_states
-        h = self.mlp(self.post_attention_layernorm(hidden_states))
-        return (residual + h,)
+        residual, h = self.post_attention_layernorm.add_and_norm(h, residual)   # residual + h, and its norm
+        return (residual + self.mlp(h),)
 
 
 class InfiniteVLTextStack(nn.Module):
@@ -140,6 +163,15 @@ class InfiniteVLTextStack(nn.Module):
                 p_.normal_(0.0, 0.3, generator=gen)
             else:
                 p_.normal_(0.0, std, generator=gen)
+        return self
+
+    @torch.no_grad()
+    def fuse_(self) -> "InfiniteVLTextStack":
+        """Inference-time weight fusion (call after loading / casting the weights): q|k|v(|g|a|b) and gate|up
+        projections become single GEMMs; parameter names, shapes and the state_dict stay as in the reference."""
+        for layer in self.layers:
+            layer.self_attn.fuse_()
+            layer.mlp.fuse_()
         return self
 
     def allocate_inference_cache(self, batch_size: int = 1, dtype: Optional[torch.dtype] = None,

@@ -73,6 +73,28 @@ class InfiniteVLSelfAttention(nn.Module):
         self.sliding_window = (config.sliding_window
                                if config.layer_types[self.layer_idx] == "sliding_attention" else None)
         self.rotary_emb = InfiniteVLRotaryEmbedding(config=config)
+        self._fused_w = self._fused_b = None
+
+    @torch.no_grad()
+    def fuse_(self) -> "InfiniteVLSelfAttention":
+        """Inference-time: store q|k|v projection weights/biases in ONE tensor (one GEMM instead of three)
+        and re-point the original parameters at views of it -- names, shapes and state_dict are unchanged
+        and no memory is duplicated."""
+        ws = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
+        bs = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
+        self._fused_w = torch.cat([w.data for w in ws], dim=0).contiguous()
+        self._fused_b = torch.cat([b.data for b in bs], dim=0).contiguous()
+        r = 0
+        for w, b in zip(ws, bs):
+            n = w.shape[0]
+            w.data = self._fused_w[r:r + n]
+            b.data = self._fused_b[r:r + n]
+            r += n
+        return self
+
+    def _fused_ok(self, x: torch.Tensor) -> bool:
+        return (self._fused_w is not None and x.dtype == torch.bfloat16 and self._fused_w.dtype == torch.bfloat16
+                and self.q_proj.weight.data_ptr() == self._fused_w.data_ptr() and self.head_dim % 16 == 0)
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.LongTensor] = None, past_key_values=None,
@@ -80,12 +102,20 @@ class InfiniteVLSelfAttention(nn.Module):
                 cache_position: Optional[torch.LongTensor] = None,
                 position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, **kwargs):
         bsz, q_len, _ = hidden_states.size()
-        # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
-        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
         cos, sin = position_embeddings
-        ops.apply_mrope_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])       # std:1057-1064
+        # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
+        if self._fused_ok(hidden_states):
+            nq, nkv = self.num_heads * self.head_dim, self.num_key_value_heads * self.head_dim
+            qkv = torch.nn.functional.linear(hidden_states, self._fused_w, self._fused_b)     # [B,T,nq+2nkv]
+            q = qkv[..., :nq].unflatten(-1, (self.num_heads, self.head_dim))
+            k = qkv[..., nq:nq + nkv].unflatten(-1, (self.num_key_value_heads, self.head_dim))
+            v = qkv[..., nq + nkv:].unflatten(-1, (self.num_key_value_heads, self.head_dim))
+            ops.apply_mrope_strided_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])
+        else:
+            q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+            k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            ops.apply_mrope_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])   # std:1057-1064
 
         layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
         if isinstance(layer, StaticSlidingWindowLayerPrealloc):
@@ -154,6 +184,71 @@ class GatedDeltaNet(nn.Module):
         self.g_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_v_dim, bias=False)
         self.o_norm = ops.FusedRMSNormGated(self.head_v_dim, eps=self.norm_eps)
         self.o_proj = nn.Linear(self.num_heads * self.head_v_dim, self.hidden_size, bias=False)
+        self._fused_w = None
+        self._fused_cols = None
+        self._gate32 = None
+
+    @torch.no_grad()
+    def fuse_(self) -> "GatedDeltaNet":
+        """Inference-time: q|k|v|g|a|b projection weights in ONE tensor (one GEMM instead of six; rows padded
+        to a multiple of 8) with the original parameters re-pointed at views of it (names/shapes/state_dict
+        unchanged, no duplicated memory), plus fp32 copies of A_log / dt_bias for the gate math."""
+        ws = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
+              self.a_proj.weight, self.b_proj.weight]
+        total = sum(w.shape[0] for w in ws)
+        ld = (total + 7) // 8 * 8
+        fused = torch.zeros(ld, self.hidden_size, dtype=ws[0].dtype, device=ws[0].device)
+        cols, r = [], 0
+        for w in ws:
+            n = w.shape[0]
+            fused[r:r + n].copy_(w.data)
+            w.data = fused[r:r + n]
+            cols.append(r)
+            r += n
+        self._fused_w = fused
+        self._fused_cols = cols                      # q, k, v, g, a, b
+        self._gate32 = (self.A_log.detach().float().contiguous(), self.dt_bias.detach().float().contiguous())
+        return self
+
+    def _fused_ok(self, x: torch.Tensor, layer) -> bool:
+        return (self._fused_w is not None and x.dtype == torch.bfloat16 and self._fused_w.dtype == torch.bfloat16
+                and self.q_proj.weight.data_ptr() == self._fused_w.data_ptr()
+                and (layer is None or (isinstance(layer, StaticLinearLayerPrealloc) and layer.dtype == torch.bfloat16))
+                and self.q_conv1d.weight.dtype == torch.bfloat16)
+
+    def _forward_fused(self, hidden_states: torch.Tensor, past_key_values, layer, cache_position, mode: str):
+        """One projection GEMM -> one prologue launch (3 convs + gate math) -> delta-rule kernel (state in place)
+        -> gated norm reading its gate from the projection buffer -> o_proj."""
+        B, T, _ = hidden_states.shape
+        H, K, V = self.num_heads, self.head_dim, self.head_v_dim
+        Dq, Dk, Dv = H * K, self.key_dim, self.value_dim
+        cq, ck, cv, cg, ca, cb = self._fused_cols
+        proj = torch.nn.functional.linear(hidden_states, self._fused_w)               # [B,T,ld]
+        ld = proj.shape[-1]
+        prev = (None, None, None)
+        h0 = None
+        if layer is not None:                                                          # std:1241-1251
+            prev, h0 = past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None,
+                                              conv_state=None, recurrent_state=None,
+                                              cache_kwargs={"op": "get", "cache_position": cache_position})
+            outs = (layer.conv_state_q, layer.conv_state_k, layer.conv_state_v)
+        else:
+            outs = (None, None, None)
+        q, k, v, g, beta = ops.gdn_prologue(
+            proj, (cq, ck, cv, ca, cb), (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight),
+            prev, outs, self._gate32[0], self._gate32[1], H, Dq, Dk, Dv)
+        fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+        o, _ = fn(q=q.view(B, T, H, K), k=k.view(B, T, self.num_key_value_heads, K), v=v.view(B, T, H, V), g=g,
+                  beta=beta, initial_state=h0, use_qk_l2norm_in_kernel=True,
+                  final_state_out=layer.recurrent_state if layer is not None else None)
+        if layer is not None:                                                          # std:1325-1333
+            past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
+                                   recurrent_state=layer.recurrent_state,
+                                   cache_kwargs={"op": "set", "delta_len": T, "cache_position": cache_position})
+        w = self.o_norm.weight
+        o = ops.rmsnorm_swish_gate_strided(o, proj[..., cg:], ld, w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16),
+                                           self.norm_eps)
+        return self.o_proj(o.reshape(B, T, -1)), None
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 past_key_values=None, cache_position: Optional[torch.LongTensor] = None, **kwargs):
@@ -164,6 +259,8 @@ class GatedDeltaNet(nn.Module):
             raise NotImplementedError("variable-length inputs are not used by InfiniteVL (std:1223)")
 
         layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
+        if self._fused_ok(hidden_states, layer):
+            return self._forward_fused(hidden_states, past_key_values, layer, cache_position, mode)
         use_cache = past_key_values is not None
         native = isinstance(layer, StaticLinearLayerPrealloc)
         prev_conv, recurrent_state = (None, None, None), None

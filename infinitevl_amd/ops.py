@@ -244,6 +244,85 @@ class FusedRMSNormGated(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------
+# fused prologue / epilogue
+# ---------------------------------------------------------------------------------------------
+def gdn_prologue(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv_states_out, A_log32, dt_bias32,
+                 H: int, Dq: int, Dk: int, Dv: int):
+    """3 short convs (+SiLU, carry-in) + gate math from ONE fused projection output.
+    proj [B,T,ld] bf16 (contiguous rows); cols = (col_q, col_k, col_v, col_a, col_b); conv_weights 3 x [D,1,4]
+    bf16; conv_states_in 3 x ([B,D,4] bf16 or None); conv_states_out likewise (may alias the inputs).
+    Returns q [B,T,Dq], k [B,T,Dk], v [B,T,Dv] bf16, g fp32 [B,T,H], beta bf16 [B,T,H]."""
+    _need_gpu(proj)
+    B, T, ld = proj.shape
+    assert proj.is_contiguous() and proj.dtype == torch.bfloat16
+    dev = proj.device
+    q = torch.empty(B, T, Dq, dtype=torch.bfloat16, device=dev)
+    k = torch.empty(B, T, Dk, dtype=torch.bfloat16, device=dev)
+    v = torch.empty(B, T, Dv, dtype=torch.bfloat16, device=dev)
+    g = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+    beta = torch.empty(B, T, H, dtype=torch.bfloat16, device=dev)
+    wq, wk, wv = conv_weights
+    si, so = conv_states_in, conv_states_out
+    _lib.check(_lib.load().ivl_gdn_prologue_fwd(
+        _p(proj), ld, cols[0], cols[1], cols[2], cols[3], cols[4], _p(wq), _p(wk), _p(wv),
+        _p(si[0]), _p(si[1]), _p(si[2]), _p(so[0]), _p(so[1]), _p(so[2]), _p(A_log32), _p(dt_bias32),
+        _p(q), _p(k), _p(v), _p(g), _p(beta), B, T, H, Dq, Dk, Dv, wq.shape[-1], 1, _stream(proj)))
+    return q, k, v, g, beta
+
+
+def rmsnorm_swish_gate_strided(x: torch.Tensor, gate_base: torch.Tensor, gate_ld: int, weight: torch.Tensor,
+                               eps: float) -> torch.Tensor:
+    """Gated RMSNorm with the gate read in place from a fused projection buffer.  x [B,T,H,256] bf16
+    contiguous; gate_base = view whose data_ptr is the gate block's first element, row stride gate_ld."""
+    _need_gpu(x, gate_base)
+    B, T, H, N = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().ivl_rmsnorm_swish_gate_strided_fwd(_p(x), _p(gate_base), gate_ld, H, _p(weight), _p(y),
+                                                              B * T * H, N, float(eps), _stream(x)))
+    return y
+
+
+def add_rmsnorm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float):
+    """h = x + residual (bf16) ; y = RMSNorm(h) * weight, one launch.  Returns (y, h); with residual=None, h is x."""
+    _need_gpu(x, residual)
+    if x.dtype != torch.bfloat16:
+        raise ValueError("add_rmsnorm is built for bf16")
+    N = x.shape[-1]
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    h = torch.empty_like(x) if residual is not None else None
+    w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+    _lib.check(_lib.load().ivl_add_rmsnorm_fwd(_p(x), _p(residual.contiguous()) if residual is not None else None,
+                                               _p(w), _p(y), _p(h), x.numel() // N, N, float(eps), _stream(x)))
+    return y, (h if h is not None else x)
+
+
+def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
+    """SwiGLU gate on a fused gate|up projection [..., 2I] -> [..., I]."""
+    _need_gpu(gate_up)
+    assert gate_up.is_contiguous() and gate_up.dtype == torch.bfloat16
+    I = gate_up.shape[-1] // 2
+    y = torch.empty(*gate_up.shape[:-1], I, dtype=torch.bfloat16, device=gate_up.device)
+    _lib.check(_lib.load().ivl_silu_mul_fwd(_p(gate_up), _p(y), gate_up.numel() // (2 * I), I, _stream(gate_up)))
+    return y
+
+
+def apply_mrope_strided_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mrope_section):
+    """M-RoPE in place on q [B,T,Hq,d] / k [B,T,Hkv,d] VIEWS into a fused qkv projection (row = token)."""
+    _need_gpu(q, k, cos, sin)
+    B, T, Hq, d = q.shape
+    Hkv = k.shape[2]
+    assert q.stride(3) == 1 and q.stride(2) == d and k.stride(3) == 1 and k.stride(2) == d
+    assert q.stride(0) == T * q.stride(1) and k.stride(0) == T * k.stride(1)
+    cos = cos.to(torch.bfloat16).contiguous()
+    sin = sin.to(torch.bfloat16).contiguous()
+    s0, s1, s2 = (int(s) for s in mrope_section)
+    _lib.check(_lib.load().ivl_mrope_strided_fwd(_p(q), _p(k), q.stride(1), k.stride(1), _p(cos), _p(sin),
+                                                 B, T, Hq, Hkv, d, s0, s1, s2, _stream(q)))
+    return q, k
+
+
+# ---------------------------------------------------------------------------------------------
 # sliding-window attention
 # ---------------------------------------------------------------------------------------------
 def apply_mrope_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mrope_section):

@@ -297,21 +297,89 @@ def test_swa_ring_path_equals_concatenated_path():
 # ---------------------------------------------------------------------------------------------
 # layers, harness (row H), hipGraph, clone, constant memory
 # ---------------------------------------------------------------------------------------------
-def test_layer_stack_vs_oracle():
-    r = parity.layer_parity(DEV, T_prefill=130, n_decode=3, window=96, seed=0)
+@pytest.mark.parametrize("fuse", [False, True])
+def test_layer_stack_vs_oracle(fuse):
+    """fuse=False: one kernel per reference operator (operator-level drop-in);
+    fuse=True: fused projections + prologue/epilogue kernels (module-level fast path)."""
+    r = parity.layer_parity(DEV, T_prefill=130, n_decode=3, window=96, seed=0, fuse=fuse)
     for name in ("prefill", "stream", "decode0", "decode1", "decode2"):
         assert r[name] < 1.5e-2, r
     assert r["gdn_state"] < 1.5e-2 and r["swa_keys"] < 6e-3, r
 
 
-def _small_stack(window=96, seed=3):
+def _small_stack(window=96, seed=3, fuse=True):
     from infinitevl_amd.harness import InfiniteVLTextStack
     from oracle import model as omodel
     hc, oc = parity.small_configs(window)
     params = parity.bf16_params(omodel.random_params(oc, seed=seed, vocab=hc.vocab_size))
     stack = InfiniteVLTextStack(hc)
     parity.load_params(stack, params)
-    return stack.to(DEV, torch.bfloat16).eval(), hc, oc, params
+    stack = stack.to(DEV, torch.bfloat16).eval()
+    if fuse:
+        stack.fuse_()
+    return stack, hc, oc, params
+
+
+def test_fused_kernels_equal_unfused_kernels():
+    """The fused prologue/epilogue kernels keep the rounding points of the single-purpose ones: conv outputs,
+    states, gates, rope and norms are bit-identical; only the GEMM fusion may reorder fp32 accumulation."""
+    from infinitevl_amd import ops
+    torch.manual_seed(11)
+    B, T, H, K, V = 2, 37, 4, 128, 256
+    Dq, Dk, Dv = H * K, H * K, H * V
+    cols = (0, Dq, Dq + Dk, Dq + Dk + Dv + H * V, Dq + Dk + Dv + H * V + H)
+    ld = (cols[4] + H + 7) // 8 * 8
+    proj = bf(torch.randn(B, T, ld)).to(DEV)
+    ws = [bf(torch.randn(D, 1, 4) * 0.4).to(DEV) for D in (Dq, Dk, Dv)]
+    st = [bf(torch.randn(B, D, 4)).to(DEV) for D in (Dq, Dk, Dv)]
+    A_log, dt = torch.randn(H).to(DEV), torch.randn(H).to(DEV)
+    st_f = [s_.clone() for s_ in st]
+    q, k, v, g, beta = ops.gdn_prologue(proj, cols, ws, st_f, st_f, A_log, dt, H, Dq, Dk, Dv)
+    outs, sts = [], []
+    for i, (c0, D) in enumerate(zip(cols[:3], (Dq, Dk, Dv))):
+        conv = ops.ShortConvolution(D, 4).to(DEV, torch.bfloat16)
+        with torch.no_grad():
+            conv.weight.copy_(ws[i])
+        s_i = st[i].clone()
+        y, s_i = conv(proj[..., c0:c0 + D].contiguous(), cache=s_i, output_final_state=True)
+        outs.append(y)
+        sts.append(s_i)
+    g2, b2 = ops.gdn_gate(proj[..., cols[3]:cols[3] + H].contiguous(), proj[..., cols[4]:cols[4] + H].contiguous(), A_log, dt)
+    for a_, b_ in zip((q, k, v), outs):
+        assert torch.equal(a_, b_)
+    for a_, b_ in zip(st_f, sts):
+        assert torch.equal(a_, b_)
+    assert torch.equal(g, g2) and torch.equal(beta, b2)
+    # gated norm with the gate read in place
+    o = bf(torch.randn(B, T, H, V)).to(DEV)
+    norm = ops.FusedRMSNormGated(V).to(DEV, torch.bfloat16)
+    cg = Dq + Dk + Dv
+    y1 = norm(o, proj[..., cg:cg + H * V].reshape(B, T, H, V).contiguous())
+    y2 = ops.rmsnorm_swish_gate_strided(o, proj[..., cg:], ld, norm.weight, norm.eps)
+    assert torch.equal(y1, y2)
+    # add + rmsnorm vs torch bf16 eager (Qwen2RMSNorm arithmetic)
+    x, r = bf(torch.randn(3, 50, 2048)).to(DEV), bf(torch.randn(3, 50, 2048)).to(DEV)
+    w = bf(1 + 0.1 * torch.randn(2048)).to(DEV)
+    y, h = ops.add_rmsnorm(x, r, w, 1e-6)
+    h_ref = r + x
+    xf = h_ref.float()
+    y_ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+    assert torch.equal(h, h_ref) and rms_rel(y_ref.float().cpu(), y.float().cpu()) < 2e-3
+    # SwiGLU gate vs torch bf16 eager
+    gu = bf(torch.randn(5, 7, 2 * 1376)).to(DEV)
+    ref = torch.nn.functional.silu(gu[..., :1376]) * gu[..., 1376:]
+    assert torch.equal(ops.silu_mul(gu), ref)
+    # strided M-RoPE vs contiguous M-RoPE
+    qkv = bf(torch.randn(2, 9, (4 + 2 + 2) * 128)).to(DEV)
+    pos = torch.arange(9)[None, None, :].expand(3, 2, 9).contiguous()
+    cos, sin = oswa.rotary_cos_sin(pos, 128, 1e6)
+    qc = qkv[..., :512].reshape(2, 9, 4, 128).contiguous()
+    kc = qkv[..., 512:768].reshape(2, 9, 2, 128).contiguous()
+    ops.apply_mrope_inplace(qc, kc, bf(cos).to(DEV), bf(sin).to(DEV), [16, 24, 24])
+    qv = qkv[..., :512].unflatten(-1, (4, 128))
+    kv = qkv[..., 512:768].unflatten(-1, (2, 128))
+    ops.apply_mrope_strided_inplace(qv, kv, bf(cos).to(DEV), bf(sin).to(DEV), [16, 24, 24])
+    assert torch.equal(qv, qc) and torch.equal(kv, kc)
 
 
 def test_hipgraph_step_is_bit_exact_with_eager_and_fixes_frozen_window():

@@ -146,7 +146,7 @@ def bf16_params(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3, window: int = 96,
-                 seed: int = 0, stream_T: int = 70) -> Dict[str, float]:
+                 seed: int = 0, stream_T: int = 70, fuse: bool = False) -> Dict[str, float]:
     """4-layer stack (1 SWA + 3 GDN), real head dims: prefill (chunk path) -> streaming frame (chunk path,
     carry-in conv, ring wrap) -> decode steps (recurrent path), HIP modules vs oracle with bf16 activations."""
     from infinitevl_amd.harness import InfiniteVLTextStack
@@ -155,6 +155,8 @@ def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3
     stack = InfiniteVLTextStack(hc)
     load_params(stack, params)
     stack = stack.to(device=device, dtype=torch.bfloat16).eval()
+    if fuse:
+        stack.fuse_()          # fused projections + prologue/epilogue kernels
     cache = stack.allocate_inference_cache(1)
     ocache = omodel.new_cache(oc, cache_dtype=torch.bfloat16)
     g_ = torch.Generator().manual_seed(seed + 1)
