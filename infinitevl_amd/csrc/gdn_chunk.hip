@@ -54,20 +54,36 @@ __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >
 // ==================================================================================================
 // LDS map (bytes).  Row strides are padded so 16-byte fragment reads of 32 consecutive rows spread banks.
 constexpr int P_LDK = 136;                         // bf16 elements per row of kh/qh/kb/stage (272 B)
-constexpr int P_LDT = 72;                          // bf16 elements per row of kbT/vbT/TwB/TuB (144 B)
+constexpr int P_LDV = 264;                         // bf16 elements per row of vb (528 B)
 constexpr int P_LDF = 68;                          // f32 elements per row of L / T (16-byte aligned rows)
 constexpr int P_LDY = 33;
-constexpr int P_KH = 0;
-constexpr int P_QH = P_KH + GC * P_LDK * 2;        // later: TwB (kh region later: TuB)
-constexpr int P_KB = P_QH + GC * P_LDK * 2;        // later: output staging
-constexpr int P_KBT = P_KB + GC * P_LDK * 2;
-constexpr int P_VBT = P_KBT + GK * P_LDT * 2;
-constexpr int P_L = P_VBT + GV * P_LDT * 2;
+constexpr int P_KH = 0;                            // k_hat            [64][136] bf16
+constexpr int P_QH = P_KH + GC * P_LDK * 2;        // q_hat            [64][136]
+constexpr int P_KB = P_QH + GC * P_LDK * 2;        // bf16(beta k_hat) [64][136]; later: Wg output staging
+constexpr int P_VB = P_KB + GC * P_LDK * 2;        // bf16(beta v)     [64][264]  (row-major: B operands via
+constexpr int P_L = P_VB + GC * P_LDV * 2;         //                   the LDS transpose read, no transposed copy)
 constexpr int P_T = P_L + GC * P_LDF * 4;
 constexpr int P_Y = P_T + GC * P_LDF * 4;
-constexpr int P_SM = P_Y + 32 * P_LDY * 4;         // gam[64], beta[64], eg[64]
-constexpr int P_BYTES = P_SM + 3 * GC * 4;
+constexpr int P_SM = P_Y + 32 * P_LDY * 4;         // gam[64], beta[64], eg[64], dec[64]
+constexpr int P_BYTES = P_SM + 4 * GC * 4;
 static_assert(P_BYTES <= 160 * 1024, "pre-pass LDS budget");
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// 32x32x16 MFMA B fragment taken from a ROW-MAJOR LDS tile X[k][n] (row stride ld elements) with the gfx950
+// transpose read: lane needs X[k0 + 8(lane>>5) + e][n0 + (lane&31)], e = 0..7.  Each 16-lane group reads a
+// 4x16 block (lane i supplies the address of row i>>2, columns 4(i&3)..+3 and receives column i).
+__device__ __forceinline__ u32x4 bfrag_tr(const bf16_t* X, int ld, int k0, int n0, int lane) {
+  const int i = lane & 15, gq = lane >> 4;
+  const bf16_t* p = X + (k0 + 8 * (gq >> 1) + (i >> 2)) * ld + n0 + 16 * (gq & 1) + 4 * (i & 3);
+  const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ld));
+  u32x2 w0, w1;
+  __builtin_memcpy(&w0, &a0, 8);
+  __builtin_memcpy(&w1, &a1, 8);
+  return u32x4{w0.x, w0.y, w1.x, w1.y};
+}
 
 // fp32 16x16 tile product on v_mfma_f32_16x16x4_f32 from LDS operands: acc += A[a_r0.., a_c0..] * B[b_r0.., b_c0..]
 __device__ __forceinline__ f32x4 tile16_f32(f32x4 acc, const float* A, int lda, int a_r0, int a_c0,
@@ -94,14 +110,14 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
   bf16_t* s_kb = (bf16_t*)(smem + P_KB);
-  bf16_t* s_kbT = (bf16_t*)(smem + P_KBT);
-  bf16_t* s_vbT = (bf16_t*)(smem + P_VBT);
+  bf16_t* s_vb = (bf16_t*)(smem + P_VB);
   float* s_L = (float*)(smem + P_L);
   float* s_T = (float*)(smem + P_T);
   float* s_Y = (float*)(smem + P_Y);
   float* s_gam = (float*)(smem + P_SM);
   float* s_beta = s_gam + GC;
   float* s_eg = s_beta + GC;
+  float* s_dec = s_eg + GC;
   bf16_t* s_stage = (bf16_t*)(smem + P_KB);
 
   trace_stamp(trace, 0);
@@ -146,99 +162,75 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       const float up = __shfl_up(gv, o, 64);
       if (lane >= o) gv += up;
     }
+    const float gl = __shfl(gv, nvalid - 1, 64);     // gamma at the last VALID token
     s_gam[lane] = gv;
     s_beta[lane] = bv;
     const float e = __expf(gv);
     s_eg[lane] = e;
+    s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
     ((float*)(rec + WS_EG))[lane] = e;
-    const float gl = __shfl(gv, nvalid - 1, 64);     // gamma at the last VALID token
     if (lane == 0) *(float*)(rec + WS_EGL) = __expf(gl);
   }
+  trace_stamp(trace, 8);
   // zero T (upper blocks stay zero)
   for (int i = tid; i < GC * P_LDF; i += 256) s_T[i] = 0.f;
-  __syncthreads();
-  const float gam_last = s_gam[nvalid - 1];
+  trace_stamp(trace, 9);
 
-  trace_stamp(trace, 1);
-  if (dbg_stop == 1) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
-  // ---- S1: l2norm, bf16; kh,qh,kb row-major, kbT transposed, Qh -> global, KdT -> global ---------
+  // ---- S1a (independent of beta/gamma, overlaps S0): l2norm -> k_hat, q_hat (bf16) to LDS -------------
+  float kf[4][8];
   {
-    float kf[4][8], qf[4][8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * rg + r;
       const bool ok = row < nvalid;
+      float qf[8];
       const u32x4 kv = kraw[r], qv = qraw[r];
       kf[r][0] = bflo(kv.x); kf[r][1] = bfhi(kv.x); kf[r][2] = bflo(kv.y); kf[r][3] = bfhi(kv.y);
       kf[r][4] = bflo(kv.z); kf[r][5] = bfhi(kv.z); kf[r][6] = bflo(kv.w); kf[r][7] = bfhi(kv.w);
-      qf[r][0] = bflo(qv.x); qf[r][1] = bfhi(qv.x); qf[r][2] = bflo(qv.y); qf[r][3] = bfhi(qv.y);
-      qf[r][4] = bflo(qv.z); qf[r][5] = bfhi(qv.z); qf[r][6] = bflo(qv.w); qf[r][7] = bfhi(qv.w);
+      if (r == 0 && __float_as_uint(kf[0][0]) != 0x7fc12345u) trace_stamp(trace, 10);
+      qf[0] = bflo(qv.x); qf[1] = bfhi(qv.x); qf[2] = bflo(qv.y); qf[3] = bfhi(qv.y);
+      qf[4] = bflo(qv.z); qf[5] = bfhi(qv.z); qf[6] = bflo(qv.w); qf[7] = bfhi(qv.w);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { kf[r][c] = ok ? kf[r][c] : 0.f; qf[r][c] = ok ? qf[r][c] : 0.f; }
+      for (int c = 0; c < 8; ++c) { kf[r][c] = ok ? kf[r][c] : 0.f; qf[c] = ok ? qf[c] : 0.f; }
       if (l2norm) {
         float ks = 0.f, qs = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { ks = fmaf(kf[r][c], kf[r][c], ks); qs = fmaf(qf[r][c], qf[r][c], qs); }
+        for (int c = 0; c < 8; ++c) { ks = fmaf(kf[r][c], kf[r][c], ks); qs = fmaf(qf[c], qf[c], qs); }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { ks += __shfl_xor(ks, o, 64); qs += __shfl_xor(qs, o, 64); }
         const float rk = 1.0f / sqrtf(ks + 1e-6f), rq = 1.0f / sqrtf(qs + 1e-6f);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { kf[r][c] = bf_round(kf[r][c] * rk); qf[r][c] = bf_round(qf[r][c] * rq); }
+        for (int c = 0; c < 8; ++c) { kf[r][c] = bf_round(kf[r][c] * rk); qf[c] = qf[c] * rq; }
       }
+      *(u32x4*)(s_kh + row * P_LDK + 8 * oct) =
+          u32x4{pack2bf(kf[r][0], kf[r][1]), pack2bf(kf[r][2], kf[r][3]), pack2bf(kf[r][4], kf[r][5]), pack2bf(kf[r][6], kf[r][7])};
+      *(u32x4*)(s_qh + row * P_LDK + 8 * oct) =
+          u32x4{pack2bf(qf[0], qf[1]), pack2bf(qf[2], qf[3]), pack2bf(qf[4], qf[5]), pack2bf(qf[6], qf[7])};
     }
-    float kd[4][8], kbv[4][8];
+  }
+  trace_stamp(trace, 11);
+  __syncthreads();
+
+  trace_stamp(trace, 1);
+  if (dbg_stop == 1) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
+  // ---- S1b: bf16(beta k_hat), bf16(beta v) row-major to LDS -------------------------------------------
+  {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * rg + r;
       const float bt = s_beta[row];
-      const float dec = __expf(gam_last - s_gam[row]);
-      u32x4 w_kh, w_qh, w_kb;
-      unsigned int* pk = (unsigned int*)&w_kh;
-      unsigned int* pq = (unsigned int*)&w_qh;
-      unsigned int* pb = (unsigned int*)&w_kb;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        kbv[r][c] = bf_round(kf[r][c] * bt);
-        kd[r][c] = kf[r][c] * dec;              // padded rows: k = 0
-      }
-#pragma unroll
-      for (int c2 = 0; c2 < 4; ++c2) {
-        pk[c2] = pack2bf(kf[r][2 * c2], kf[r][2 * c2 + 1]);
-        pq[c2] = pack2bf(qf[r][2 * c2], qf[r][2 * c2 + 1]);
-        pb[c2] = pack2bf(kbv[r][2 * c2], kbv[r][2 * c2 + 1]);
-      }
-      *(u32x4*)(s_kh + row * P_LDK + 8 * oct) = w_kh;
-      *(u32x4*)(s_qh + row * P_LDK + 8 * oct) = w_qh;
-      *(u32x4*)(s_kb + row * P_LDK + 8 * oct) = w_kb;
-      *(u32x4*)(rec + WS_QH + ((size_t)row * GK + 8 * oct) * 2) = w_qh;
+      *(u32x4*)(s_kb + row * P_LDK + 8 * oct) =
+          u32x4{pack2bf(kf[r][0] * bt, kf[r][1] * bt), pack2bf(kf[r][2] * bt, kf[r][3] * bt),
+                pack2bf(kf[r][4] * bt, kf[r][5] * bt), pack2bf(kf[r][6] * bt, kf[r][7] * bt)};
     }
-    // transposed copies: column (8 oct + c), rows 4rg..4rg+3  (8 bytes)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      u32x2 wb, wd;
-      wb.x = pack2bf(kbv[0][c], kbv[1][c]); wb.y = pack2bf(kbv[2][c], kbv[3][c]);
-      wd.x = pack2bf(kd[0][c], kd[1][c]);   wd.y = pack2bf(kd[2][c], kd[3][c]);
-      *(u32x2*)(s_kbT + (8 * oct + c) * P_LDT + 4 * rg) = wb;
-      *(u32x2*)(rec + WS_KDT + ((size_t)(8 * oct + c) * GC + 4 * rg) * 2) = wd;
-    }
-  }
-  // ---- S1b: v (8 rows x 8 cols per thread) -> vbT = bf16(beta v)^T -----------------------------
-  {
-    float vf[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = 8 * vrg + r;
       const u32x4 vv = vraw[r];
       const float bt = s_beta[row];               // 0 for padded rows
-      vf[r][0] = bflo(vv.x) * bt; vf[r][1] = bfhi(vv.x) * bt; vf[r][2] = bflo(vv.y) * bt; vf[r][3] = bfhi(vv.y) * bt;
-      vf[r][4] = bflo(vv.z) * bt; vf[r][5] = bfhi(vv.z) * bt; vf[r][6] = bflo(vv.w) * bt; vf[r][7] = bfhi(vv.w) * bt;
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      u32x4 w;
-      w.x = pack2bf(vf[0][c], vf[1][c]); w.y = pack2bf(vf[2][c], vf[3][c]);
-      w.z = pack2bf(vf[4][c], vf[5][c]); w.w = pack2bf(vf[6][c], vf[7][c]);
-      *(u32x4*)(s_vbT + (8 * voct + c) * P_LDT + 8 * vrg) = w;
+      *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
+          u32x4{pack2bf(bflo(vv.x) * bt, bfhi(vv.x) * bt), pack2bf(bflo(vv.y) * bt, bfhi(vv.y) * bt),
+                pack2bf(bflo(vv.z) * bt, bfhi(vv.z) * bt), pack2bf(bflo(vv.w) * bt, bfhi(vv.w) * bt)};
     }
   }
   __syncthreads();
@@ -373,14 +365,14 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-    const bf16_t* brow = s_kbT + (32 * wave + l31) * P_LDT + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < GC / 16; ++ks) {
-      const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
+      const u32x4 bfr = bfrag_tr(s_kb, P_LDK, 16 * ks, 32 * wave, lane);     // (beta k)[time][col 32w + l31]
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(twf[mi][ks]), mf(bfr), acc[mi], 0, 0, 0);
     }
+    __syncthreads();          // every wave has read its kb fragments before the region is reused for staging
     // Wg = bf16(bf16(w) * e^gamma_i) staged row-major in the (dead) kb region
     const int j = 32 * wave + l31;
 #pragma unroll
@@ -392,10 +384,27 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       }
   }
   __syncthreads();
-  // coalesced copy-out of Wg (64 rows x 256 B)
+  // coalesced copy-out of Wg and Qh (64 rows x 256 B each)
   for (int idx = tid; idx < GC * (GK / 8); idx += 256) {
     const int row = idx >> 4, ch = idx & 15;
     *(u32x4*)(rec + WS_WG + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_stage + row * P_LDK + 8 * ch);
+    *(u32x4*)(rec + WS_QH + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_qh + row * P_LDK + 8 * ch);
+  }
+  // KdT[kidx][time] = bf16(k_hat[time][kidx] * e^{gamma_last - gamma_time}): thread = (kidx, 32-token half),
+  // one 64-byte run per thread
+  {
+    const int c = tid & 127, half = tid >> 7;
+    unsigned int pk[16];
+#pragma unroll
+    for (int t2 = 0; t2 < 16; ++t2) {
+      const int t = 32 * half + 2 * t2;
+      const float a0 = bf2f(s_kh[t * P_LDK + c]) * s_dec[t];
+      const float a1 = bf2f(s_kh[(t + 1) * P_LDK + c]) * s_dec[t + 1];
+      pk[t2] = pack2bf(a0, a1);
+    }
+    u32x4* dst = (u32x4*)(rec + WS_KDT + ((size_t)c * GC + 32 * half) * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]};
   }
 
   trace_stamp(trace, 6);
@@ -410,10 +419,9 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
       const int col = 64 * wave + 32 * nj + l31;
-      const bf16_t* brow = s_vbT + col * P_LDT + 8 * hi;
 #pragma unroll
       for (int ks = 0; ks < GC / 16; ++ks) {
-        const u32x4 bfr = *(const u32x4*)(brow + 16 * ks);
+        const u32x4 bfr = bfrag_tr(s_vb, P_LDV, 16 * ks, 64 * wave + 32 * nj, lane);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(tuf[mi][ks]), mf(bfr), acc[mi], 0, 0, 0);

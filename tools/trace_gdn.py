@@ -31,6 +31,7 @@ for it in range(3):
     print(f"--- iter {it}: prepare kernel (cycles since kernel start)")
     for i in range(1, 8):
         print(f"   {names[i]:14s} +{t[i]-t[i-1]:8d}   (cum {t[i]-t[0]})")
+    print(f"   [S0 detail] wave0 g/beta+cumsum done +{t[8]-t[0]}  zeroT done +{t[9]-t[0]}  first k data +{t[10]-t[0]}  S1a done(before barrier) +{t[11]-t[0]}")
     print("    scan kernel")
     print(f"   entry->frags0 issue     {t[17]-t[16]:8d}")
     for ci in range(min(4, (T + 63) // 64)):
