@@ -71,6 +71,17 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
   const int hi = n_prev + t_row;
   const int lo = p.W > 0 ? max(0, n_prev + t_row - p.W + 1) : 0;
 
+  // band extremes over the rows of THIS wave (rows are consecutive; lo/hi are monotone in the row index)
+  int w_lo_max, w_hi_min;
+  {
+    const int wr0 = tile_row0 + wave * 16;
+    const int wr1 = min(wr0 + 15, total_rows - 1);
+    const int t_first = PACK ? wr0 / G : wr0;
+    const int t_last = PACK ? max(wr1, wr0) / G : max(wr1, wr0);
+    w_hi_min = n_prev + t_first;
+    w_lo_max = p.W > 0 ? max(0, n_prev + t_last - p.W + 1) : 0;
+  }
+
   // workgroup key-tile range
   const int last_row = min(tile_row0 + SWA_QT, total_rows) - 1;
   const int t_min = PACK ? tile_row0 / G : tile_row0;
@@ -156,23 +167,35 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
       }
     }
     // ---- band mask + online softmax (lane-local row) ------------------------------------------
+    // Interior tiles (every key visible to every row of this wave) skip the per-element band test.
     const int jbase = kt * SWA_KT + 4 * g;
+    const bool interior = kt * SWA_KT >= w_lo_max && kt * SWA_KT + SWA_KT - 1 <= w_hi_min;
     float rmax = -INFINITY;
+    if (interior) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = jbase + 16 * mt + r;
-        const bool vis = row_ok && j >= lo && j <= hi;
-        const float s = vis ? sacc[mt][r] * sc : -INFINITY;
-        sacc[mt][r] = s;
-        rmax = fmaxf(rmax, s);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const float s = sacc[mt][r] * sc;
+          sacc[mt][r] = s;
+          rmax = fmaxf(rmax, s);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jbase + 16 * mt + r;
+          const bool vis = row_ok && j >= lo && j <= hi;
+          const float s = vis ? sacc[mt][r] * sc : -INFINITY;
+          sacc[mt][r] = s;
+          rmax = fmaxf(rmax, s);
+        }
+    }
     rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
     const float m_new = fmaxf(m_run, rmax);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);          // m_run = -inf -> 0
     float rsum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -184,10 +207,15 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
       }
     rsum += __shfl_xor(rsum, 16, 64);
     rsum += __shfl_xor(rsum, 32, 64);
-    l_run = l_run * alpha + rsum;
-    m_run = m_new;
+    if (__any(m_new > m_run)) {                          // some row's running max moved: rescale (exact)
+      const float alpha = exp2f(m_run - m_use);          // m_run = -inf -> 0
+      l_run = l_run * alpha + rsum;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) oacc[i] *= alpha;
+      for (int i = 0; i < 8; ++i) oacc[i] *= alpha;
+    } else {
+      l_run += rsum;
+    }
+    m_run = m_new;
 
     // ---- P^T fragments (B operand): slots 8g+e <-> keys 32ks2+4g+e | 32ks2+16+4g+(e-4) ---------
     u32x4 pf[2];
@@ -258,7 +286,9 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
   }
 }
 
-// merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane
+// merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane; every split's loads are
+// issued before the first use (template on the split count so the loop is fully unrolled)
+template <int NS>
 __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                          bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit) {
   const int lane = threadIdx.x & 63;
@@ -266,17 +296,27 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
   const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
   for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
     const long long b = r / rows_per_b, rr = r % rows_per_b;
+    float ms[NS], ls[NS];
+    float2 ov[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bool on = s < nsplit;
+      const long long pr = (b * nsplit + (on ? s : 0)) * rows_per_b + rr;
+      const float2 ml = *(const float2*)(part_ml + pr * 2);
+      ms[s] = on ? ml.x : -INFINITY;
+      ls[s] = on ? ml.y : 0.f;
+      ov[s] = *(const float2*)(part_o + pr * SWA_D + 2 * lane);
+    }
     float m = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[((b * nsplit + s) * rows_per_b + rr) * 2]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) m = fmaxf(m, ms[s]);
     float l = 0.f, a0 = 0.f, a1 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const long long pr = (b * nsplit + s) * rows_per_b + rr;
-      const float ms = part_ml[pr * 2];
-      const float w = ms == -INFINITY ? 0.f : exp2f(ms - m);
-      l += w * part_ml[pr * 2 + 1];
-      const float2 ov = *(const float2*)(part_o + pr * SWA_D + 2 * lane);
-      a0 = fmaf(w, ov.x, a0);
-      a1 = fmaf(w, ov.y, a1);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float w = ms[s] == -INFINITY ? 0.f : exp2f(ms[s] - m);
+      l = fmaf(w, ls[s], l);
+      a0 = fmaf(w, ov[s].x, a0);
+      a1 = fmaf(w, ov[s].y, a1);
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     *(unsigned int*)(o + r * SWA_D + 2 * lane) = pack2bf(a0 * inv, a1 * inv);
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(256) void swa_cache_append_kernel(
 
 static int swa_base_nsplit(int B, int T, int Hq) {
   const long long base = (long long)B * ((T + SWA_QT - 1) / SWA_QT) * Hq;
-  long long ns = (1024 + base - 1) / base;
+  long long ns = (512 + base - 1) / base;
   if (ns < 1) ns = 1;
   if (ns > SWA_MAX_SPLIT) ns = SWA_MAX_SPLIT;
   return (int)ns;
@@ -394,7 +434,9 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     const long long nrows = (long long)a->B * a->T * a->Hq;
     long long gb = (nrows * 64 + 255) / 256;
     if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(swa_combine_kernel, dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    else hipLaunchKernelGGL((swa_combine_kernel<16>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
     rc = check_launch("ivl_swa_fwd(combine)");
   }
   return rc;
