@@ -27,6 +27,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _enable_tunableop():
+    """The dense projections / MLP are stock rocBLAS / hipBLASLt GEMMs reached through torch (out of the
+    path's scope); let PyTorch's own TunableOp pick the library kernel per GEMM shape (+6 % prefill, +35 %
+    decode at these M=256 / M=1 shapes).  A results file recorded on gfx950 / ROCm 7.2 is shipped and
+    pre-seeded per rank; shapes it does not cover are tuned during the warm-up steps (seconds)."""
+    if os.environ.get("IVL_NO_TUNABLEOP") == "1":
+        return
+    import shutil
+    import tempfile
+    rank = os.environ.get("LOCAL_RANK", "0")
+    d = tempfile.mkdtemp(prefix=f"ivl_tunableop_r{rank}_")
+    seed = os.path.join(ROOT, "infinitevl_amd", "tuning", "tunableop_gfx950_rocm72.csv")
+    if os.path.exists(seed):
+        for ordinal in range(8):
+            shutil.copy(seed, os.path.join(d, f"results{ordinal}.csv"))
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(d, "results.csv"))
+
+
+_enable_tunableop()
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
