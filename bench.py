@@ -94,55 +94,52 @@ def event_time_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / (iters * reps)
 
 
-def kernel_timings(device, chunk, window):
-    """Per-launch time of every hot-path kernel at the bench shapes (B=1, T=chunk, real head shapes,
-    full window), each measured live with HIP events on the stream it is launched on."""
+def kernel_timings(device, chunk, window, only=None):
+    """Per-launch GPU time of every hot-path kernel at the bench shapes (B=1, T=chunk, InfiniteVL-3B head
+    shapes, full window), plus two throughput-regime shapes (T=4096) for the two heavy kernels.  Each entry:
+    ms per launch, launches per prefill step, the roofline that bounds it, algorithmic bytes/flops per
+    launch and the achieved rate."""
     from infinitevl_amd import ops
     st = torch.cuda.current_stream(device)
     B, T, H, K, V, Hq, Hkv, d = 1, chunk, 16, 128, 256, 16, 2, 128
     g_ = torch.Generator(device=device).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=device, generator=g_).to(torch.bfloat16)  # noqa: E731
-    q, k, v = rn(B, T, H, K), rn(B, T, H, K), rn(B, T, H, V)
-    beta = torch.rand(B, T, H, device=device, generator=g_).to(torch.bfloat16)
-    g = torch.nn.functional.logsigmoid(torch.randn(B, T, H, device=device, generator=g_))
-    state = (torch.randn(B, H, K, V, device=device, generator=g_)).to(torch.bfloat16)
+    C = window - 1
     res = {}
 
-    t = event_time_ms(lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state,
-                                                         use_qk_l2norm_in_kernel=True, final_state_out=state), 20, st)
-    gdn_bytes = 24672.0 * T + 2 * H * K * V * 4          # SURVEY.md 8d: per-token bytes + fp32 state r+w per call
-    res["gdn_chunk(prepare+scan)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=gdn_bytes,
-                                          achieved=gdn_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    # SWA prefill step: T queries over a full ring (W-1 cached keys) + T new keys
-    C = window - 1
+    def add(name, fn, iters, per_step, bound, work):
+        if only is not None and only not in name:
+            return
+        ms = event_time_ms(fn, iters, st)
+        if bound == "hbm":
+            res[name] = dict(ms=ms, launches_per_step=per_step, bound="hbm", alg_bytes=work,
+                             achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        else:
+            res[name] = dict(ms=ms, launches_per_step=per_step, bound="mfma", alg_flops=work,
+                             achieved=work / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+        res[name]["frac"] = res[name]["achieved"] / res[name]["peak"]
+
+    def gdn_inputs(Tn):
+        q, k, v = rn(B, Tn, H, K), rn(B, Tn, H, K), rn(B, Tn, H, V)
+        beta = torch.rand(B, Tn, H, device=device, generator=g_).to(torch.bfloat16)
+        g = torch.nn.functional.logsigmoid(torch.randn(B, Tn, H, device=device, generator=g_))
+        return q, k, v, g, beta
+
+    state = torch.randn(B, H, K, V, device=device, generator=g_).to(torch.bfloat16)
+    # GDN bytes: 24,672 B/token/layer + fp32 state read+write per call (SURVEY.md 8d)
+    q, k, v, g, beta = gdn_inputs(T)
+    add("gdn_chunk(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
+        q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
+        20, 27, "hbm", 24672.0 * T + 2 * H * K * V * 4)
+    # SWA prefill: T queries over a full ring (W-1 cached keys) + T new keys; 8192*min(p+1,W) FLOP/token/layer
     kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
     pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
     qs, kn, vn = rn(B, T, Hq, d), rn(B, T, Hkv, d), rn(B, T, Hkv, d)
-    t = event_time_ms(lambda: ops.swa_forward(qs, kn, vn, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
-                                              pos_dev=pos_dev), 50, st)
-    swa_flops = 4.0 * Hq * d * window * T                 # SURVEY.md 8d: 8192*min(p+1,W) FLOP/token/layer
-    res["swa_prefill"] = dict(ms=t, launches_per_step=9, bound="mfma", alg_flops=swa_flops,
-                              achieved=swa_flops / (t * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
-    t = event_time_ms(lambda: ops.swa_cache_append(kn, vn, kc, vc, pos_dev=pos_dev), 50, st)
-    res["swa_cache_append"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=4.0 * T * Hkv * d * 2,
-                                   achieved=4.0 * T * Hkv * d * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    # decode-shape kernels
-    q1, k1, v1 = rn(B, 1, H, K), rn(B, 1, H, K), rn(B, 1, H, V)
-    b1 = torch.rand(B, 1, H, device=device, generator=g_).to(torch.bfloat16)
-    g1 = torch.nn.functional.logsigmoid(torch.randn(B, 1, H, device=device, generator=g_))
-    t = event_time_ms(lambda: ops.fused_recurrent_gated_delta_rule(q1, k1, v1, g1, b1, initial_state=state,
-                                                                   use_qk_l2norm_in_kernel=True, final_state_out=state), 100, st)
-    rec_bytes = 24672.0 + 2 * H * K * V * 2               # bf16 cache state read + write
-    res["gdn_recurrent(decode)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=rec_bytes,
-                                        achieved=rec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    qd = rn(B, 1, Hq, d)
-    kd1, vd1 = rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
-    t = event_time_ms(lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
-                                              pos_dev=pos_dev), 100, st)
-    dec_bytes = 1024.0 * window                           # SURVEY.md 8d: 1024*min(p+1,W) B/token/layer
-    res["swa_decode"] = dict(ms=t, launches_per_step=9, bound="hbm", alg_bytes=dec_bytes,
-                             achieved=dec_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    # fused prologue (3 convs + gate math from one projection buffer) and gated norm at T=chunk
+    add("swa_prefill", lambda: ops.swa_forward(qs, kn, vn, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
+                                               pos_dev=pos_dev), 20, 9, "mfma", 4.0 * Hq * d * window * T)
+    add("swa_cache_append", lambda: ops.swa_cache_append(kn, vn, kc, vc, pos_dev=pos_dev), 50, 9, "hbm",
+        4.0 * T * Hkv * d * 2)
+    # fused prologue (3 convs + gate math from one projection buffer), gated norm, decoder-layer norm
     Dq, Dk, Dv = H * K, H * K, H * V
     cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
     ld = cols[4] + H
@@ -150,21 +147,30 @@ def kernel_timings(device, chunk, window):
     cw = [rn(D_, 1, 4) for D_ in (Dq, Dk, Dv)]
     cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
     A32, dt32 = torch.randn(H, device=device, generator=g_), torch.randn(H, device=device, generator=g_)
-    t = event_time_ms(lambda: ops.gdn_prologue(proj, cols, cw, cs, cs, A32, dt32, H, Dq, Dk, Dv), 50, st)
-    pro_bytes = 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2)
-    res["gdn_prologue(3 convs + gates)"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=pro_bytes,
-                                               achieved=pro_bytes / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    xo = rn(B, T, H, V)
-    wn = rn(V)
-    t = event_time_ms(lambda: ops.rmsnorm_swish_gate_strided(xo, proj[..., Dq + Dk + Dv:], ld, wn, 1e-5), 50, st)
-    res["rmsnorm_swish_gate"] = dict(ms=t, launches_per_step=27, bound="hbm", alg_bytes=3.0 * T * H * V * 2,
-                                     achieved=3.0 * T * H * V * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    add("gdn_prologue(3 convs + gates)", lambda: ops.gdn_prologue(proj, cols, cw, cs, cs, A32, dt32, H, Dq, Dk, Dv),
+        50, 27, "hbm", 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2))
+    xo, wn = rn(B, T, H, V), rn(V)
+    add("rmsnorm_swish_gate", lambda: ops.rmsnorm_swish_gate_strided(xo, proj[..., Dq + Dk + Dv:], ld, wn, 1e-5),
+        50, 27, "hbm", 3.0 * T * H * V * 2)
     xh, rh, wh = rn(B, T, 2048), rn(B, T, 2048), rn(2048)
-    t = event_time_ms(lambda: ops.add_rmsnorm(xh, rh, wh, 1e-6), 50, st)
-    res["add_rmsnorm(decoder layer)"] = dict(ms=t, launches_per_step=72, bound="hbm", alg_bytes=4.0 * T * 2048 * 2,
-                                            achieved=4.0 * T * 2048 * 2 / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    for r in res.values():
-        r["frac"] = r["achieved"] / r["peak"]
+    add("add_rmsnorm(decoder layer)", lambda: ops.add_rmsnorm(xh, rh, wh, 1e-6), 50, 72, "hbm", 4.0 * T * 2048 * 2)
+    # decode-shape kernels (per decode token, not per prefill step)
+    q1, k1, v1, g1, b1 = gdn_inputs(1)
+    add("gdn_recurrent(decode)", lambda: ops.fused_recurrent_gated_delta_rule(
+        q1, k1, v1, g1, b1, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
+        100, 27, "hbm", 24672.0 + 2 * H * K * V * 2)
+    qd, kd1, vd1 = rn(B, 1, Hq, d), rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
+    add("swa_decode", lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
+                                              pos_dev=pos_dev), 100, 9, "hbm", 1024.0 * window)
+    # throughput-regime shapes (one-shot 4096-token prefill, BASELINE.json configs[1]); not part of the step
+    TL = 4096
+    qL, kL, vL, gL, bL = gdn_inputs(TL)
+    add("gdn_chunk@T=4096", lambda: ops.chunk_gated_delta_rule(
+        qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
+        5, 0, "hbm", 24672.0 * TL + 2 * H * K * V * 4)
+    qsL, knL, vnL = rn(B, TL, Hq, d), rn(B, TL, Hkv, d), rn(B, TL, Hkv, d)
+    add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),
+        5, 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
     return res
 
 
@@ -301,7 +307,7 @@ def main():
         if kernels is not None:
             def step_ms(r):
                 return r["ms"] * r["launches_per_step"]
-            prefill_kernels = {k: v for k, v in kernels.items() if "decode" not in k}
+            prefill_kernels = {k: v for k, v in kernels.items() if v["launches_per_step"] > 0 and "decode" not in k}
             dom = max(prefill_kernels, key=lambda k: step_ms(prefill_kernels[k]))
             r = kernels[dom]
             out["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],

@@ -4,8 +4,8 @@
 // Formulation (everything per query row stays inside one lane group; no P round trip through LDS):
 //   S^T = K Q^T      A = K tile rows (keys)      B = Q^T            -> lane owns ONE query row
 //   O^T = V^T P^T    A = V^T (LDS transpose read) B = P^T (in regs) -> same lane owns that row's O
-// A 64-key tile is staged once per workgroup (4 waves x 16 query rows) into LDS: K rows of 256 B with a
-// 16-byte-chunk XOR swizzle (conflict-free ds_read_b128 of MFMA A fragments), V rows padded to 288 B
+// A 64-key tile is staged once per workgroup (4 waves x 16 query rows) into LDS: K rows padded to 272 B
+// (ds_read_b128 of MFMA A fragments from ONE base register + immediates), V rows padded to 288 B
 // (conflict-free ds_read_b64_tr_b16).  The key -> MFMA k-slot map of the PV product is permuted so the
 // probabilities produced by the first MFMA feed the second one without any cross-lane movement:
 //   slot 8g+e  <->  key 32*ks + 4g + e (e<4)  |  key 32*ks + 16 + 4g + (e-4) (e>=4).
@@ -22,7 +22,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int SWA_D = 128;
 constexpr int SWA_QT = 64;           // query rows per workgroup
 constexpr int SWA_KT = 64;           // keys per tile
-constexpr int SWA_KSTRIDE = 256;     // bytes per K row in LDS (swizzled)
+constexpr int SWA_KSTRIDE = 272;     // bytes per K row in LDS (padded: linear addresses, <=2-way conflicts)
 constexpr int SWA_VSTRIDE = 288;     // bytes per V row in LDS (padded)
 constexpr int SWA_LDS_K = SWA_KT * SWA_KSTRIDE;
 constexpr int SWA_LDS_BYTES = SWA_LDS_K + SWA_KT * SWA_VSTRIDE;
@@ -46,7 +46,7 @@ __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
 }
 
 template <bool PACK, bool TR>
-__global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
+__global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SWA_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -111,36 +111,42 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
   // ---- staging: thread -> rows (tid>>4) + 16 i, 16-byte chunk tid&15 ------------------------------
   const int srow = tid >> 4, schunk = tid & 15;
   u32x4 kreg[4], vreg[4];
+  // per-(batch, kv-head) base pointers; rows are addressed with 32-bit element offsets from them
+  const bf16_t* kb_ring = p.C > 0 ? p.k_cache + (((long long)b * p.Hkv + hk) * p.C) * SWA_D + schunk * 8 : p.k_new;
+  const bf16_t* vb_ring = p.C > 0 ? p.v_cache + (((long long)b * p.Hkv + hk) * p.C) * SWA_D + schunk * 8 : p.v_new;
+  const bf16_t* kb_new = p.k_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
+  const bf16_t* vb_new = p.v_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
+  const unsigned int kn_st32 = (unsigned int)p.kn_st;
   auto load_tile = [&](int kt) {
-    // branch-free: every row issues its two 16-byte loads (clamped address), invalid rows are zeroed
-    // afterwards -- a conditional load per row would serialise one memory round trip per row.
+    // branch-free: every row issues its two 16-byte loads (clamped address); a conditional load per row
+    // would serialise one memory round trip per row.  Only the last tile can hold rows >= S (zeroed).
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = srow + 16 * i;
-      const int j = kt * SWA_KT + r;
-      const bool ok = j < S;
-      const int jc = ok ? j : S - 1;
+      const int j = kt * SWA_KT + srow + 16 * i;
+      const int jc = min(j, S - 1);
       const bool in_ring = jc < n_ring;
       int slot = s0 + jc;
-      if (slot >= p.C) slot -= p.C;
-      const long long off_ring = (((long long)b * p.Hkv + hk) * p.C + (in_ring ? slot : 0)) * SWA_D + schunk * 8;
-      const long long off_new = (long long)b * p.kn_sb + (long long)(in_ring ? 0 : jc - n_ring) * p.kn_st +
-                                (long long)hk * p.kn_sh + schunk * 8;
-      const bf16_t* kp = in_ring ? p.k_cache + off_ring : p.k_new + off_new;
-      const bf16_t* vp = in_ring ? p.v_cache + off_ring : p.v_new + off_new;
+      slot = slot >= p.C ? slot - p.C : slot;
+      const unsigned int off = in_ring ? (unsigned int)slot * SWA_D : (unsigned int)(jc - n_ring) * kn_st32;
+      const bf16_t* kp = (in_ring ? kb_ring : kb_new) + off;
+      const bf16_t* vp = (in_ring ? vb_ring : vb_new) + off;
       kreg[i] = *(const u32x4*)kp;
       vreg[i] = *(const u32x4*)vp;
-      if (!ok) {
-        kreg[i] = u32x4{0u, 0u, 0u, 0u};
-        vreg[i] = u32x4{0u, 0u, 0u, 0u};
-      }
+    }
+    if (kt * SWA_KT + SWA_KT > S) {          // wave-uniform: tail tile
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (kt * SWA_KT + srow + 16 * i >= S) {
+          kreg[i] = u32x4{0u, 0u, 0u, 0u};
+          vreg[i] = u32x4{0u, 0u, 0u, 0u};
+        }
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = srow + 16 * i;
-      *(u32x4*)(smem + r * SWA_KSTRIDE + ((schunk ^ (r & 15)) << 4)) = kreg[i];
+      *(u32x4*)(smem + r * SWA_KSTRIDE + schunk * 16) = kreg[i];
       *(u32x4*)(smem + SWA_LDS_K + r * SWA_VSTRIDE + schunk * 16) = vreg[i];
     }
   };
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
       const int kr = 16 * mt + l15;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kf = *(const u32x4*)(smem + kr * SWA_KSTRIDE + (((4 * ks + g) ^ (kr & 15)) << 4));
+        const u32x4 kf = *(const u32x4*)(smem + kr * SWA_KSTRIDE + (4 * ks + g) * 16);
         sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(kf), as_mfma(qf[ks]), sacc[mt], 0, 0, 0);
       }
     }
@@ -201,14 +207,14 @@ __global__ __launch_bounds__(256) void swa_fwd_kernel(SwaParams p) {
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = exp2f(sacc[mt][r] - m_use);
+        const float pv = __builtin_amdgcn_exp2f(sacc[mt][r] - m_use);    // arguments <= 0: raw v_exp_f32
         sacc[mt][r] = pv;
         rsum += pv;
       }
     rsum += __shfl_xor(rsum, 16, 64);
     rsum += __shfl_xor(rsum, 32, 64);
     if (__any(m_new > m_run)) {                          // some row's running max moved: rescale (exact)
-      const float alpha = exp2f(m_run - m_use);          // m_run = -inf -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run = -inf -> 0
       l_run = l_run * alpha + rsum;
 #pragma unroll
       for (int i = 0; i < 8; ++i) oacc[i] *= alpha;

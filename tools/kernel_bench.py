@@ -21,11 +21,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--window", type=int, default=4096)
     ap.add_argument("--json", default="")
+    ap.add_argument("--only", default=None)
     args = ap.parse_args()
     import infinitevl_amd
     infinitevl_amd.load_library()
     dev = torch.device("cuda", 0)
-    res = bench.kernel_timings(dev, args.chunk, args.window)
+    res = bench.kernel_timings(dev, args.chunk, args.window, only=args.only)
     for k, v in res.items():
         print(f"{k:34s} {v['ms'] * 1e3:9.2f} us/launch  x{v['launches_per_step']:3d}/step  "
               f"{v['achieved']:9.1f} {v['unit']:8s} frac={v['frac']:.4f}")
