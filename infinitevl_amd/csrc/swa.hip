@@ -33,7 +33,7 @@ struct SwaParams {
   const bf16_t* q; const bf16_t* k_new; const bf16_t* v_new; const bf16_t* k_cache; const bf16_t* v_cache;
   bf16_t* o;
   long long q_sb, q_st, q_sh, kn_sb, kn_st, kn_sh;
-  int B, T, T_new, Hq, Hkv, C, W, nsplit;
+  int B, T, T_new, Hq, Hkv, C, W, nsplit, n_qtiles;
   long long pos; const long long* pos_dev;
   float scaling;
   float* part_o; float* part_ml;
@@ -51,8 +51,21 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int G = p.Hq / p.Hkv;
-  const int b = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
-  const int hk = PACK ? (int)blockIdx.y : (int)blockIdx.y / G;
+  // 1-D grid with an XCD-aware (bijective) remap: hardware block id i runs on XCD i % 8; logical ids are
+  // ordered (b, split, kv-head, head-in-group, q-tile) so the workgroups that read the SAME K/V range are
+  // consecutive and therefore land on the same XCD / L2 (they re-read each K/V tile up to 8 x n_qtiles times).
+  int lid;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = nwg >> 3, rn = nwg & 7;
+    lid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int heads_y = PACK ? p.Hkv : p.Hq;
+  const int bx = lid % p.n_qtiles;                       // q-tile
+  const int by = (lid / p.n_qtiles) % heads_y;           // q head (or kv head when PACK); heads of one group adjacent
+  const int bz = lid / (p.n_qtiles * heads_y);           // b * nsplit + split
+  const int b = bz / p.nsplit, split = bz % p.nsplit;
+  const int hk = PACK ? by : by / G;
 
   const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
@@ -63,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 
   // ---- rows of this workgroup / wave / lane ----------------------------------------------------
   const int total_rows = PACK ? p.T * G : p.T;
-  const int tile_row0 = blockIdx.x * SWA_QT;
+  const int tile_row0 = bx * SWA_QT;
   const int row = tile_row0 + wave * 16 + l15;
   const bool row_ok = row < total_rows;
   const int t_row = PACK ? row / G : row;
-  const int hq = PACK ? hk * G + row % G : (int)blockIdx.y;
+  const int hq = PACK ? hk * G + row % G : by;
   const int hi = n_prev + t_row;
   const int lo = p.W > 0 ? max(0, n_prev + t_row - p.W + 1) : 0;
 
@@ -424,7 +437,8 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     p.part_ml = p.part_o + n_o;
   }
   const int rows = pack ? a->T * G : a->T;
-  dim3 grid((rows + SWA_QT - 1) / SWA_QT, pack ? a->Hkv : a->Hq, a->B * nsplit);
+  p.n_qtiles = (rows + SWA_QT - 1) / SWA_QT;
+  dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
   hipStream_t st = (hipStream_t)stream;
   const bool tr = swa_use_tr();
   if (pack) {
