@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
 // ==================================================================================================
 constexpr int S_LDS = 136;     // bf16 per row of S^T  [32 cols][128 k]   (272 B)
 constexpr int S_LDV = 72;      // bf16 per row of v_new^T [32 cols][64 t] (144 B)
+constexpr int S_LDO = 40;      // bf16 per row of the output staging tile [64 t][32 cols] (80 B)
 
 __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
     const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
@@ -453,12 +454,15 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
     int T, int H, int t_seg0, int nt_seg, float scale, long long* trace) {
   __shared__ __attribute__((aligned(16))) bf16_t s_st[G_BV * S_LDS];
   __shared__ __attribute__((aligned(16))) bf16_t s_vn[G_BV * S_LDV];
+  __shared__ __attribute__((aligned(16))) bf16_t s_o[GC * S_LDO];
 
   trace_stamp(trace, 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int v0 = blockIdx.x * G_BV;
-  const int bh = blockIdx.y;
+  // grid = (B*H, V/32): linear block id = bh + B*H*slab, so with B*H % 8 == 0 the 8 V-slabs of one head run on
+  // the same XCD (id % 8) and share its L2 for the operands they all read (Wg/Qh/KdT/Aqk).
+  const int v0 = blockIdx.y * G_BV;
+  const int bh = blockIdx.x;
   const int b = bh / H, h = bh % H;
   const bool is_p = wave < 2;                 // waves 0,1: v_new rows 32*wave.. ; waves 2,3: output rows 32*(wave-2)..
   const int mrow0 = 32 * (wave & 1);
@@ -520,12 +524,20 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
     }
   }
 
+  // coalesced store of a finished 64x32 output tile from LDS: thread -> (row tid>>2, 8 columns), 16 bytes
+  auto flush_o = [&](int tc0) {
+    const int row = tid >> 2, part = tid & 3;
+    const int t = tc0 + row;
+    if (t < T) *(u32x4*)(o + (((size_t)b * T + t) * H + h) * GV + v0 + 8 * part) = *(const u32x4*)(s_o + row * S_LDO + 8 * part);
+  };
+
   // one chunk of the recurrence with the operands in `f` ---------------------------------------------
   auto chunk_step = [&](const Frags& f, int ci) {
     const int tc0 = t_seg0 + ci * GC;
     if (ci < 4) trace_stamp(trace, 18 + 4 * ci);
     // ---- (i) publish the state slab as bf16 S^T[col][k] -----------------------------------------
-    __syncthreads();          // previous chunk's readers of s_st / s_vn are done
+    __syncthreads();          // previous chunk's readers of s_st / s_vn are done, its output tile is in s_o
+    if (ci > 0) flush_o(tc0 - GC);
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       u32x2 w;
@@ -588,10 +600,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       for (int ks = 0; ks < 4; ++ks)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(f.aqfr[ks]), mf(vfr[ks]), acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = tc0 + mrow0 + crow32(r, hi);
-        if (t < T) o[(((size_t)b * T + t) * H + h) * GV + v0 + l31] = f2bf(acc[r] * scale);
-      }
+      for (int r = 0; r < 16; ++r) s_o[(mrow0 + crow32(r, hi)) * S_LDO + l31] = f2bf(acc[r] * scale);
     }
     if (ci < 4) trace_stamp(trace, 21 + 4 * ci);
   };
@@ -606,6 +615,8 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       chunk_step(fb, ci + 1);
     }
   }
+  __syncthreads();
+  flush_o(t_seg0 + (nt_seg - 1) * GC);
   trace_stamp(trace, 34);
 
   if (ht != nullptr) {
@@ -675,7 +686,7 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
     if (dbg_skip_scan) continue;
-    hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(GV / G_BV, B * H), dim3(256), 0, st,
+    hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(B * H, GV / G_BV), dim3(256), 0, st,
                        (const unsigned char*)wsb, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale, debug_trace_buffer());
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
