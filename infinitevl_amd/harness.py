@@ -19,6 +19,10 @@ import torch.nn.functional as F
 
 from . import ops
 from .cache import StaticCachePrealloc
+
+import os as _os
+
+_XLAYER_FUSE = _os.environ.get("IVL_NO_XLAYER_FUSE") != "1"     # A/B knob for the cross-layer add+norm fusion
 from .modules import GatedDeltaNet, InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
 
 
@@ -191,12 +195,27 @@ class InfiniteVLTextStack(nn.Module):
             start = past_key_values.get_seq_length() if past_key_values is not None else 0
             position_ids = torch.arange(start, start + T, device=inputs_embeds.device)[None, None, :].expand(3, B, T)
         position_embeddings = self.rotary_emb(inputs_embeds, position_ids)           # std:1549
-        h = inputs_embeds
+        # The residual add that ends a decoder layer (std:1422) is fused into the NEXT layer's input RMSNorm
+        # (one add+norm launch instead of add, norm): `resid` is the residual stream, `pend` the not-yet-added
+        # MLP output of the previous layer.
+        resid, pend = inputs_embeds, None
+        _xl = _XLAYER_FUSE
         for layer in self.layers:                                                    # std:1555-1571
-            h = layer(h, position_ids=position_ids, past_key_values=past_key_values,
-                      use_cache=past_key_values is not None, cache_position=cache_position,
-                      position_embeddings=position_embeddings)[0]
-        h = self.norm(h)
+            if not _xl and pend is not None:
+                resid, pend = resid + pend, None
+            if pend is None:
+                y = layer.input_layernorm(resid)
+            else:
+                resid, y = layer.input_layernorm.add_and_norm(pend, resid)
+            attn, _ = layer.self_attn(hidden_states=y, position_ids=position_ids, past_key_values=past_key_values,
+                                      use_cache=past_key_values is not None, cache_position=cache_position,
+                                      position_embeddings=position_embeddings)
+            resid, y = layer.post_attention_layernorm.add_and_norm(attn, resid)
+            pend = layer.mlp(y)
+        if pend is None:
+            h = self.norm(resid)
+        else:
+            _, h = self.norm.add_and_norm(pend, resid)
         logits = None
         if logits_to_keep:
             logits = F.linear(h[:, -logits_to_keep:, :], self.embed_tokens.weight)  # tied lm_head (std:2091-2092)
