@@ -494,3 +494,45 @@ def test_constant_memory_over_a_long_stream():
         torch.cuda.synchronize()
         assert peak <= base, (peak, base, peak - base)
         assert cache.get_seq_length() == 80 * 256 and torch.isfinite(gs.hidden.float()).all()
+
+
+def test_full_size_model_streams_512k_tokens_in_constant_memory():
+    """BASELINE.json configs[3]/north_star: "constant memory verified to 512K tokens".  The real InfiniteVL-3B
+    decoder shape (36 layers, hidden 2048, 16/2 heads, GDN state 16x128x256, window 4096; random-init bf16),
+    one sequence, 2048 hipGraph steps x 256 tokens = 524,288 tokens: device memory does not grow by a byte
+    after the window is full, the device/host counters agree, and activations stay finite."""
+    import gc
+    from infinitevl_amd.harness import GraphedStep, InfiniteVLTextConfig, InfiniteVLTextStack
+    cfg = InfiniteVLTextConfig(sliding_window=4096)
+    with torch.device(DEV):
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            model = InfiniteVLTextStack(cfg)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    model = model.to(torch.bfloat16).eval()
+    model.init_weights_(seed=0).fuse_()
+    with torch.no_grad():
+        cache = model.allocate_inference_cache(1)
+        gs = GraphedStep(model, cache, 1, 256, logits_to_keep=1)
+        g_ = torch.Generator(device=DEV).manual_seed(7)
+        frames = [(torch.randn(1, 256, cfg.hidden_size, device=DEV, generator=g_) * 0.02).to(torch.bfloat16) for _ in range(3)]
+        for i in range(20):                      # 5120 tokens: window (4095 keys) full
+            gs.step(frames[i % 3])
+        torch.cuda.synchronize()
+        gc.collect()
+        base, peak = torch.cuda.memory_allocated(), 0
+        for i in range(20, 2048):
+            gs.step(frames[i % 3])
+            if i % 256 == 0:
+                peak = max(peak, torch.cuda.memory_allocated())
+        torch.cuda.synchronize()
+        peak = max(peak, torch.cuda.memory_allocated())
+        assert peak <= base, (peak, base)
+        assert cache.get_seq_length() == 2048 * 256 == 524288
+        assert int(cache.layers[0]._pos_dev.item()) == 524288 and cache.layers[0].size == 4095
+        assert torch.isfinite(gs.hidden.float()).all() and torch.isfinite(gs.logits.float()).all()
+        assert cache.memory_bytes() < 80 * 2 ** 20          # 27 MiB GDN state + 1.7 MiB conv + 37.7 MB SWA ring
+    del model, gs, cache
+    gc.collect()
+    torch.cuda.empty_cache()
