@@ -108,7 +108,10 @@ def kernel_timings(device, chunk, window, only=None):
     res = {}
 
     def add(name, fn, iters, per_step, bound, work):
-        if only is not None and only not in name:
+        if only == "!large":
+            if "@T=" in name:
+                return
+        elif only is not None and only not in name:
             return
         ms = event_time_ms(fn, iters, st)
         if bound == "hbm":
@@ -172,6 +175,32 @@ def kernel_timings(device, chunk, window, only=None):
     add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),
         5, 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
     return res
+
+
+def pmc_traffic(kernel_name, chunk, window):
+    """HBM-side bytes per launch of a hot-path kernel from the committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_traffic.json, produced by tools/collect_profiles.sh on this same command's kernels at the
+    default bench shapes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot
+    run the PMC passes itself, so the newest committed measurement is attached; null when the shapes differ."""
+    import glob
+    if chunk != 256 or window != 4096:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"]
+    parts = {
+        "gdn_chunk(prepare+scan)": ["ivl::gdn_chunk_prepare_kernel@grid16384", "ivl::gdn_chunk_scan_kernel@grid32768"],
+        "swa_prefill": ["ivl::swa_fwd_kernel<false, true>@grid131072", "ivl::swa_combine_kernel<8>@grid262144"],
+        "gdn_prologue(3 convs + gates)": ["ivl::gdn_prologue_kernel@grid36864"],
+        "add_rmsnorm(decoder layer)": ["ivl::add_rmsnorm_kernel@grid65536"],
+        "rmsnorm_swish_gate": ["ivl::rmsnorm_gate_strided_kernel@grid131072"],
+        "gdn_recurrent(decode)": ["ivl::gdn_recurrent_kernel@grid32768"],
+    }.get(kernel_name)
+    if not parts or any(p_ not in k for p_ in parts):
+        return None
+    return {"hbm_bytes": sum(k[p_]["hbm_bytes"] for p_ in parts), "source": os.path.basename(files[-1]),
+            "launches": parts}
 
 
 def cpu_baseline(chunk, window):
@@ -310,8 +339,11 @@ def main():
             prefill_kernels = {k: v for k, v in kernels.items() if v["launches_per_step"] > 0 and "decode" not in k}
             dom = max(prefill_kernels, key=lambda k: step_ms(prefill_kernels[k]))
             r = kernels[dom]
+            tr = pmc_traffic(dom, T, args.window)
             out["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
-                               "unit": r["unit"], "frac": r["frac"], "traffic": None,
+                               "unit": r["unit"], "frac": r["frac"], "traffic": tr["hbm_bytes"] if tr else None,
+                               "traffic_source": tr["source"] if tr else None,
+                               "algorithmic_per_launch": r.get("alg_bytes", r.get("alg_flops")),
                                "avg_launch_ms": r["ms"], "launches_per_step": r["launches_per_step"]}
             out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                               for k, v in kernels.items()}

@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench
     python $REPO/bench.py --steps 64 --warmup 4 --decode-steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp /tmp/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $REPO/tools/kernel_bench.py > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $REPO/tools/kernel_bench.py --only '!large' > /dev/null 2>&1
 done
 python - <<PY
 import csv, collections, json
