@@ -207,8 +207,16 @@ class GatedDeltaNet(nn.Module):
             r += n
         self._fused_w = fused
         self._fused_cols = cols                      # q, k, v, g, a, b
-        self._gate32 = (self.A_log.detach().float().contiguous(), self.dt_bias.detach().float().contiguous())
+        self._gate32 = None
         return self
+
+    def _gate_params32(self):
+        """fp32 copies of A_log / dt_bias for the gate math (std:1294 upcasts them per call); cached and
+        refreshed whenever the parameters are modified in place (e.g. load_state_dict after fuse_)."""
+        key = (self.A_log._version, self.dt_bias._version, self.A_log.data_ptr(), self.dt_bias.data_ptr())
+        if self._gate32 is None or self._gate32[0] != key:
+            self._gate32 = (key, self.A_log.detach().float().contiguous(), self.dt_bias.detach().float().contiguous())
+        return self._gate32[1], self._gate32[2]
 
     def _fused_ok(self, x: torch.Tensor, layer) -> bool:
         return (self._fused_w is not None and x.dtype == torch.bfloat16 and self._fused_w.dtype == torch.bfloat16
@@ -234,9 +242,10 @@ class GatedDeltaNet(nn.Module):
             outs = (layer.conv_state_q, layer.conv_state_k, layer.conv_state_v)
         else:
             outs = (None, None, None)
+        A32, dt32 = self._gate_params32()
         q, k, v, g, beta = ops.gdn_prologue(
             proj, (cq, ck, cv, ca, cb), (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight),
-            prev, outs, self._gate32[0], self._gate32[1], H, Dq, Dk, Dv)
+            prev, outs, A32, dt32, H, Dq, Dk, Dv)
         fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
         o, _ = fn(q=q.view(B, T, H, K), k=k.view(B, T, self.num_key_value_heads, K), v=v.view(B, T, H, V), g=g,
                   beta=beta, initial_state=h0, use_qk_l2norm_in_kernel=True,

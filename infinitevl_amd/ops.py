@@ -313,11 +313,15 @@ def apply_mrope_strided_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Ten
     B, T, Hq, d = q.shape
     Hkv = k.shape[2]
     assert q.stride(3) == 1 and q.stride(2) == d and k.stride(3) == 1 and k.stride(2) == d
-    assert q.stride(0) == T * q.stride(1) and k.stride(0) == T * k.stride(1)
+
+    def row_stride(t_):      # elements between consecutive tokens of the flattened [B*T] row index
+        if T > 1 and B > 1:
+            assert t_.stride(0) == T * t_.stride(1), "q/k must be row-uniform views of a [B*T, ld] buffer"
+        return t_.stride(1) if T > 1 else t_.stride(0)
     cos = cos.to(torch.bfloat16).contiguous()
     sin = sin.to(torch.bfloat16).contiguous()
     s0, s1, s2 = (int(s) for s in mrope_section)
-    _lib.check(_lib.load().ivl_mrope_strided_fwd(_p(q), _p(k), q.stride(1), k.stride(1), _p(cos), _p(sin),
+    _lib.check(_lib.load().ivl_mrope_strided_fwd(_p(q), _p(k), row_stride(q), row_stride(k), _p(cos), _p(sin),
                                                  B, T, Hq, Hkv, d, s0, s1, s2, _stream(q)))
     return q, k
 

@@ -536,3 +536,122 @@ def test_full_size_model_streams_512k_tokens_in_constant_memory():
     del model, gs, cache
     gc.collect()
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------
+# boundary behaviour: foreign cache protocol, batches, error paths, weight fusion round trip
+# ---------------------------------------------------------------------------------------------
+class _CatCache:
+    """A cache that follows the REFERENCE protocol (std:126-173): update() returns cat(cached, new) in
+    [B,H,S,d] and keeps the last W-1 tokens.  Exercises the operator-level drop-in path of
+    InfiniteVLSelfAttention (ALL_ATTENTION_FUNCTIONS-style call with concatenated K/V)."""
+
+    def __init__(self, n_layers, window):
+        self.layers = [object() for _ in range(n_layers)]
+        self.k = self.v = None
+        self.cap = window - 1
+
+    def update(self, layer_idx, key_states, value_states, conv_state, recurrent_state, cache_kwargs):
+        fk = key_states if self.k is None else torch.cat([self.k, key_states], dim=2)
+        fv = value_states if self.v is None else torch.cat([self.v, value_states], dim=2)
+        self.k, self.v = fk[:, :, -self.cap:].contiguous(), fv[:, :, -self.cap:].contiguous()
+        return fk, fv
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_swa_module_with_reference_style_cat_cache_equals_ring_cache(fuse):
+    stack, hc, _, _ = _small_stack(window=96, fuse=fuse)
+    attn = stack.layers[0].self_attn
+    rot = stack.rotary_emb
+    ring = stack.allocate_inference_cache(2)
+    cat = _CatCache(len(stack.layers), 96)
+    pos = 0
+    with torch.no_grad():
+        for T in (50, 70, 1, 1, 33):
+            x = bf(torch.randn(2, T, hc.hidden_size) * 0.5).to(DEV)
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :].expand(3, 2, T)
+            pe = rot(x, pid)
+            o1, _ = attn(x, position_ids=pid, past_key_values=ring, position_embeddings=pe)
+            o2, _ = attn(x, position_ids=pid, past_key_values=cat, position_embeddings=pe)
+            assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 4e-3, T
+            pos += T
+    assert torch.equal(ring.layers[0].keys, cat.k)          # same tokens kept, same order, bit for bit
+
+
+def test_cache_error_behaviour_on_gpu():
+    from infinitevl_amd.cache import StaticCachePrealloc
+    stack, hc, _, _ = _small_stack(window=96)
+    cache = StaticCachePrealloc(config=hc, batch_size=2, device=DEV, dtype=torch.bfloat16)
+    k = torch.zeros(1, 5, 1, 128, dtype=torch.bfloat16, device=DEV)
+    q = torch.zeros(1, 5, 2, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError, match="pre-allocated batch_size=2"):          # std:137-138
+        cache.layers[0].attend(q, k, k, 1.0, 96)
+    k2 = torch.zeros(2, 5, 2, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError, match="head dim mismatch"):                   # std:139-140
+        cache.layers[0].attend(torch.zeros(2, 5, 2, 128, dtype=torch.bfloat16, device=DEV), k2, k2, 1.0, 96)
+    with pytest.raises(ValueError, match="pre-allocated batch_size=2"):
+        cache.layers[0].update(k.transpose(1, 2), k.transpose(1, 2))
+
+
+def test_fuse_keeps_state_dict_and_reloads():
+    """fuse_() must not change parameter names/shapes/values, and loading a checkpoint AFTER fusing must
+    update the fused tensors (parameters are views of them)."""
+    from oracle import model as omodel
+    stack, hc, oc, params = _small_stack(window=96, fuse=False)
+    before = {k: v.clone() for k, v in stack.state_dict().items()}
+    stack.fuse_()
+    after = stack.state_dict()
+    assert list(before) == list(after)
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    new = parity.bf16_params(omodel.random_params(oc, seed=99, vocab=hc.vocab_size))
+    stack.load_state_dict({k: v.to(torch.bfloat16) for k, v in new.items()}, strict=False)
+    gdn = stack.layers[1].self_attn
+    assert gdn.q_proj.weight.data_ptr() == gdn._fused_w.data_ptr()                # still views
+    assert torch.equal(gdn._fused_w[gdn._fused_cols[5]:gdn._fused_cols[5] + 2].float().cpu(),
+                       new["layers.1.self_attn.b_proj.weight"])
+    x = bf(torch.randn(1, 70, hc.hidden_size) * 0.5)
+    pid = torch.arange(70)[None, None, :].expand(3, 1, 70).contiguous()
+    with torch.no_grad():
+        h, _ = stack(inputs_embeds=x.to(DEV), position_ids=pid.to(DEV), past_key_values=stack.allocate_inference_cache(1))
+    h_ref = omodel.text_stack(new, x.float(), pid, oc, omodel.new_cache(oc, torch.bfloat16), torch.bfloat16, torch.bfloat16)
+    assert rms_rel(h_ref, h.float().cpu()) < 1.5e-2
+
+
+def test_fp32_cache_state_option():
+    """The build may keep the carried GDN state in fp32 (SURVEY.md Q5 option): a float32 cache works through the
+    same modules (conv states converted, recurrent state written in place as fp32)."""
+    stack, hc, _, _ = _small_stack(window=96, fuse=True)
+    c32 = stack.allocate_inference_cache(1, dtype=torch.float32)
+    c16 = stack.allocate_inference_cache(1)
+    with torch.no_grad():
+        pos = 0
+        for T in (130, 70, 1):
+            x = bf(torch.randn(1, T, hc.hidden_size) * 0.5).to(DEV)
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :].expand(3, 1, T)
+            # SWA ring stays bf16-only: give the fp32 cache a bf16 SWA layer
+            c32.layers[0] = c16.layers[0].clone() if pos == 0 else c32.layers[0]
+            h32, _ = stack(inputs_embeds=x, position_ids=pid, past_key_values=c32)
+            h16, _ = stack(inputs_embeds=x, position_ids=pid, past_key_values=c16)
+            assert rms_rel(h32.float().cpu(), h16.float().cpu()) < 2e-2
+            pos += T
+    assert c32.layers[1].recurrent_state.dtype == torch.float32
+    assert rms_rel(c32.layers[1].recurrent_state.cpu(), c16.layers[1].recurrent_state.float().cpu()) < 2e-2
+
+
+def test_batched_streams_are_independent():
+    """Batch sharding premise: sequences in a batch do not interact -- B=3 run together ==
+    each sequence run alone, bit for bit (GDN chunk + recurrent, SWA ring, conv carry-in)."""
+    stack, hc, _, _ = _small_stack(window=96, fuse=True)
+    xs = [bf(torch.randn(3, T, hc.hidden_size) * 0.5).to(DEV) for T in (130, 70, 1, 1)]
+    with torch.no_grad():
+        cb = stack.allocate_inference_cache(3)
+        singles = [stack.allocate_inference_cache(1) for _ in range(3)]
+        pos = 0
+        for x in xs:
+            T = x.shape[1]
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :]
+            hb, _ = stack(inputs_embeds=x, position_ids=pid.expand(3, 3, T), past_key_values=cb)
+            for i in range(3):
+                hi, _ = stack(inputs_embeds=x[i:i + 1], position_ids=pid.expand(3, 1, T), past_key_values=singles[i])
+                assert rms_rel(hi.float().cpu(), hb[i:i + 1].float().cpu()) < 4e-3, (T, i)    # GEMM M differs -> fp32 order
+            pos += T
