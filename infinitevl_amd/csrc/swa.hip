@@ -37,6 +37,7 @@ struct SwaParams {
   long long pos; const long long* pos_dev;
   float scaling;
   float* part_o; float* part_ml;
+  long long* trace;
 };
 
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
@@ -164,27 +165,35 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
   };
 
+  trace_stamp(p.trace, 0);
   if (kt_begin < kt_end) load_tile(kt_begin);
   const float sc = p.scaling * LOG2E;
 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int ts = 1 + 5 * (kt - kt_begin);
+    if (kt - kt_begin < 6) trace_stamp(p.trace, ts);
     __syncthreads();
     store_tile();
     __syncthreads();
-    if (kt + 1 < kt_end) load_tile(kt + 1);
+    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 1);
 
-    // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps -------------------------------------------
+    // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps; d-step outermost so that consecutive MFMAs go to four
+    //      independent accumulators (no back-to-back dependent issue) -------------------------------------
     f32x4 sacc[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int kr = 16 * mt + l15;
+    for (int mt = 0; mt < 4; ++mt) sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kf = *(const u32x4*)(smem + kr * SWA_KSTRIDE + (4 * ks + g) * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const u32x4 kf = *(const u32x4*)(smem + (16 * mt + l15) * SWA_KSTRIDE + (4 * ks + g) * 16);
         sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(kf), as_mfma(qf[ks]), sacc[mt], 0, 0, 0);
       }
     }
+    // next tile's global loads are issued behind the first MFMA batch (their address arithmetic no longer
+    // delays it); they have the softmax + PV phases to land before store_tile of the next iteration
+    if (kt + 1 < kt_end) load_tile(kt + 1);
+    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 2);
     // ---- band mask + online softmax (lane-local row) ------------------------------------------
     // Interior tiles (every key visible to every row of this wave) skip the per-element band test.
     const int jbase = kt * SWA_KT + 4 * g;
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
     m_run = m_new;
 
+    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 3);
     // ---- P^T fragments (B operand): slots 8g+e <-> keys 32ks2+4g+e | 32ks2+16+4g+(e-4) ---------
     u32x4 pf[2];
 #pragma unroll
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
   }
 
+  trace_stamp(p.trace, 40);
   // ---- epilogue: lane owns row `row`, d = 16 mt2 + 4g + r ---------------------------------------
   if (!row_ok) return;
   if (p.nsplit == 1) {
@@ -428,6 +439,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.B = a->B; p.T = a->T; p.T_new = a->T_new; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity; p.W = a->window;
   p.nsplit = nsplit; p.pos = a->pos; p.pos_dev = (const long long*)a->pos_dev; p.scaling = a->scaling;
   p.part_o = nullptr; p.part_ml = nullptr;
+  p.trace = debug_trace_buffer();
   if (nsplit > 1) {
     const size_t n_o = (size_t)a->B * nsplit * a->T * a->Hq * SWA_D;
     const size_t need = (n_o + (size_t)a->B * nsplit * a->T * a->Hq * 2) * sizeof(float);

@@ -38,5 +38,9 @@ for it in range(3):
         b = 18 + 4 * ci
         prev = t[17] if ci == 0 else t[b - 1]
         print(f"   chunk {ci}: loads/wait {t[b]-prev:7d}  publish {t[b+1]-t[b]:7d}  mfma1+vnew {t[b+2]-t[b+1]:7d}  out+update {t[b+3]-t[b+2]:7d}")
+    for ci in (0, 2):
+        b = 40 + 4 * ci
+        if t[b]:
+            print(f"   after chunk {ci}: barrier(done reading) {t[b+1]-t[b]:6d}  write_stage(wait loads + 15 ds_write) {t[b+2]-t[b+1]:6d}  issue_loads {t[b+3]-t[b+2]:6d}")
     print(f"   loop end -> stored       {t[35]-t[34]:8d}   total scan {t[35]-t[16]}   prepare->scan gap {t[16]-t[7]}")
 lib.ivl_debug_set_trace(None)
