@@ -59,14 +59,15 @@ constexpr int P_LDF = 68;                          // f32 elements per row of L 
 constexpr int P_LDY = 33;
 constexpr int P_KH = 0;                            // k_hat            [64][136] bf16
 constexpr int P_QH = P_KH + GC * P_LDK * 2;        // q_hat            [64][136]
+constexpr int P_VB = 0;                            // bf16(beta v)     [64][264] row-major, written over k_hat/q_hat
+                                                   //   once they are dead (B operands via the LDS transpose read)
 constexpr int P_KB = P_QH + GC * P_LDK * 2;        // bf16(beta k_hat) [64][136]; later: Wg output staging
-constexpr int P_VB = P_KB + GC * P_LDK * 2;        // bf16(beta v)     [64][264]  (row-major: B operands via
-constexpr int P_L = P_VB + GC * P_LDV * 2;         //                   the LDS transpose read, no transposed copy)
-constexpr int P_T = P_L + GC * P_LDF * 4;
-constexpr int P_Y = P_T + GC * P_LDF * 4;
+constexpr int P_L = P_KB + GC * P_LDK * 2;         // L, inverted IN PLACE to T = (I+L)^-1   [64][68] f32
+constexpr int P_Y = P_L + GC * P_LDF * 4;
 constexpr int P_SM = P_Y + 32 * P_LDY * 4;         // gam[64], beta[64], eg[64], dec[64]
-constexpr int P_BYTES = P_SM + 4 * GC * 4;
-static_assert(P_BYTES <= 160 * 1024, "pre-pass LDS budget");
+constexpr int P_BYTES = P_SM + 4 * GC * 4;         // 74,880: two workgroups per CU
+static_assert(GC * P_LDV * 2 <= 2 * GC * P_LDK * 2, "vb must fit in the k_hat/q_hat region");
+static_assert(2 * P_BYTES <= 160 * 1024, "pre-pass LDS budget (2 workgroups per CU)");
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void store16_f32(float* Cm, int ldc, int r0, int c0, 
   for (int r = 0; r < 4; ++r) Cm[(r0 + 4 * g + r) * ldc + c0 + j] = sign * acc[r];
 }
 
-__global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
+__global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const float* __restrict__ g, const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws,
     int T, int H, int t_seg0, int nt_seg, int l2norm, int dbg_stop, long long* trace) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
   bf16_t* s_kb = (bf16_t*)(smem + P_KB);
   bf16_t* s_vb = (bf16_t*)(smem + P_VB);
   float* s_L = (float*)(smem + P_L);
-  float* s_T = (float*)(smem + P_T);
+  float* s_T = s_L;                          // inverted in place
   float* s_Y = (float*)(smem + P_Y);
   float* s_gam = (float*)(smem + P_SM);
   float* s_beta = s_gam + GC;
@@ -172,8 +173,6 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     if (lane == 0) *(float*)(rec + WS_EGL) = __expf(gl);
   }
   trace_stamp(trace, 8);
-  // zero T (upper blocks stay zero)
-  for (int i = tid; i < GC * P_LDF; i += 256) s_T[i] = 0.f;
   trace_stamp(trace, 9);
 
   // ---- S1a (independent of beta/gamma, overlaps S0): l2norm -> k_hat, q_hat (bf16) to LDS -------------
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
 
   trace_stamp(trace, 1);
   if (dbg_stop == 1) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
-  // ---- S1b: bf16(beta k_hat), bf16(beta v) row-major to LDS -------------------------------------------
+  // ---- S1b: bf16(beta k_hat) row-major to LDS (beta v follows once k_hat/q_hat are dead) -------------
   {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -222,15 +221,6 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       *(u32x4*)(s_kb + row * P_LDK + 8 * oct) =
           u32x4{pack2bf(kf[r][0] * bt, kf[r][1] * bt), pack2bf(kf[r][2] * bt, kf[r][3] * bt),
                 pack2bf(kf[r][4] * bt, kf[r][5] * bt), pack2bf(kf[r][6] * bt, kf[r][7] * bt)};
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int row = 8 * vrg + r;
-      const u32x4 vv = vraw[r];
-      const float bt = s_beta[row];               // 0 for padded rows
-      *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
-          u32x4{pack2bf(bflo(vv.x) * bt, bfhi(vv.x) * bt), pack2bf(bflo(vv.y) * bt, bfhi(vv.y) * bt),
-                pack2bf(bflo(vv.z) * bt, bfhi(vv.z) * bt), pack2bf(bflo(vv.w) * bt, bfhi(vv.w) * bt)};
     }
   }
   __syncthreads();
@@ -280,7 +270,28 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
 
   trace_stamp(trace, 3);
   if (dbg_stop == 3) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
-  // ---- S3: T = (I + L)^-1 ----------------------------------------------------------------------
+  // ---- Qh and KdT leave now (their stores overlap the solve); afterwards k_hat/q_hat are dead -----------
+  for (int idx = tid; idx < GC * (GK / 8); idx += 256) {
+    const int row = idx >> 4, ch = idx & 15;
+    *(u32x4*)(rec + WS_QH + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_qh + row * P_LDK + 8 * ch);
+  }
+  // KdT[kidx][time] = bf16(k_hat[time][kidx] * e^{gamma_last - gamma_time}): thread = (kidx, 32-token half),
+  // one 64-byte run per thread
+  {
+    const int c = tid & 127, half = tid >> 7;
+    unsigned int pk[16];
+#pragma unroll
+    for (int t2 = 0; t2 < 16; ++t2) {
+      const int t = 32 * half + 2 * t2;
+      const float a0 = bf2f(s_kh[t * P_LDK + c]) * s_dec[t];
+      const float a1 = bf2f(s_kh[(t + 1) * P_LDK + c]) * s_dec[t + 1];
+      pk[t2] = pack2bf(a0, a1);
+    }
+    u32x4* dst = (u32x4*)(rec + WS_KDT + ((size_t)c * GC + 32 * half) * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]};
+  }
+  // ---- S3: T = (I + L)^-1, in place ------------------------------------------------------------
   // (a) diagonal 16x16 blocks by forward substitution: wave w -> block w, lane c<16 -> column c.
   if (lane < 16) {
     const int r0 = 16 * wave, c = lane;
@@ -297,6 +308,16 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
     for (int i = 0; i < 16; ++i) s_T[(r0 + i) * P_LDF + r0 + c] = x[i];
   }
   __syncthreads();
+  // bf16(beta v) row-major over the dead k_hat/q_hat region (read by S6, several barriers later)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = 8 * vrg + r;
+    const u32x4 vv = vraw[r];
+    const float bt = s_beta[row];               // 0 for padded rows
+    *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
+        u32x4{pack2bf(bflo(vv.x) * bt, bfhi(vv.x) * bt), pack2bf(bflo(vv.y) * bt, bfhi(vv.y) * bt),
+              pack2bf(bflo(vv.z) * bt, bfhi(vv.z) * bt), pack2bf(bflo(vv.w) * bt, bfhi(vv.w) * bt)};
+  }
   // (b) 16->32: X21 = -X22 (L21 X11) for block pairs (0,1) [wave 0] and (2,3) [wave 1]
   if (wave < 2) {
     const int base = 32 * wave;
@@ -384,27 +405,10 @@ __global__ __launch_bounds__(256) void gdn_chunk_prepare_kernel(
       }
   }
   __syncthreads();
-  // coalesced copy-out of Wg and Qh (64 rows x 256 B each)
+  // coalesced copy-out of Wg (64 rows x 256 B)
   for (int idx = tid; idx < GC * (GK / 8); idx += 256) {
     const int row = idx >> 4, ch = idx & 15;
     *(u32x4*)(rec + WS_WG + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_stage + row * P_LDK + 8 * ch);
-    *(u32x4*)(rec + WS_QH + ((size_t)row * GK + 8 * ch) * 2) = *(const u32x4*)(s_qh + row * P_LDK + 8 * ch);
-  }
-  // KdT[kidx][time] = bf16(k_hat[time][kidx] * e^{gamma_last - gamma_time}): thread = (kidx, 32-token half),
-  // one 64-byte run per thread
-  {
-    const int c = tid & 127, half = tid >> 7;
-    unsigned int pk[16];
-#pragma unroll
-    for (int t2 = 0; t2 < 16; ++t2) {
-      const int t = 32 * half + 2 * t2;
-      const float a0 = bf2f(s_kh[t * P_LDK + c]) * s_dec[t];
-      const float a1 = bf2f(s_kh[(t + 1) * P_LDK + c]) * s_dec[t + 1];
-      pk[t2] = pack2bf(a0, a1);
-    }
-    u32x4* dst = (u32x4*)(rec + WS_KDT + ((size_t)c * GC + 32 * half) * 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]};
   }
 
   trace_stamp(trace, 6);
