@@ -35,12 +35,10 @@ for it in range(3):
     print("    scan kernel")
     print(f"   entry->frags0 issue     {t[17]-t[16]:8d}")
     for ci in range(min(4, (T + 63) // 64)):
-        b = 18 + 4 * ci
+        b, e = 18 + 4 * ci, 40 + 4 * ci
         prev = t[17] if ci == 0 else t[b - 1]
-        print(f"   chunk {ci}: loads/wait {t[b]-prev:7d}  publish {t[b+1]-t[b]:7d}  mfma1+vnew {t[b+2]-t[b+1]:7d}  out+update {t[b+3]-t[b+2]:7d}")
-    for ci in (0, 2):
-        b = 40 + 4 * ci
-        if t[b]:
-            print(f"   after chunk {ci}: barrier(done reading) {t[b+1]-t[b]:6d}  write_stage(wait loads + 15 ds_write) {t[b+2]-t[b+1]:6d}  issue_loads {t[b+3]-t[b+2]:6d}")
+        print(f"   chunk {ci}: gap {t[b]-prev:6d} | publish+dma_wait {t[e]-t[b]:6d} | barrier1 {t[b+1]-t[e]:6d} | "
+              f"flush+dma issue+mfma(ii) {t[e+1]-t[b+1]:6d} | vnew/eg {t[e+2]-t[e+1]:6d} | barrier2 {t[b+2]-t[e+2]:6d} | "
+              f"update+out(iii) {t[b+3]-t[b+2]:6d}")
     print(f"   loop end -> stored       {t[35]-t[34]:8d}   total scan {t[35]-t[16]}   prepare->scan gap {t[16]-t[7]}")
 lib.ivl_debug_set_trace(None)
