@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--decode-steps", type=int, default=128)
     ap.add_argument("--layers", type=int, default=36, help="debug only; the reported config is 36")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg1", action="store_true", help="skip the 4K one-call prefill + decode leg (configs[1])")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -308,6 +309,43 @@ def main():
     dec_elapsed = ivd.max_over_ranks(time.perf_counter() - t1, device)
     mem_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
+    # ---- configs[1] leg (rank 0, N=1; reported beside the headline, never mixed into `value`): one 4096-token
+    #      prefill call on a fresh cache (chunk path over 64 chunks; SWA purely causal) + 128 graphed decode steps
+    cfg1 = None
+    if rank == 0 and world == 1 and not args.no_cfg1:
+        del step, dec
+        Tp, reps = 4096, 3
+        ids = torch.randint(0, cfg.vocab_size, (1, Tp), device=device,
+                            generator=torch.Generator(device=device).manual_seed(1))
+        pid = torch.arange(Tp, device=device)[None, None, :].expand(3, 1, Tp).contiguous()
+        cache1 = model.allocate_inference_cache(1)
+        times = []
+        with torch.no_grad():
+            for r in range(reps + 1):
+                cache1.reset()
+                torch.cuda.synchronize()
+                tA = time.perf_counter()
+                _, lg = model(input_ids=ids, position_ids=pid, past_key_values=cache1, logits_to_keep=1)
+                torch.cuda.synchronize()
+                if r > 0:
+                    times.append(time.perf_counter() - tA)
+        dec1 = GraphedDecode(model, cache1, 1)
+        dec1.token.copy_(lg[:, -1].argmax(-1, keepdim=True))
+        dec1.capture()
+        for _ in range(4):
+            dec1.step()
+        torch.cuda.synchronize()
+        tA = time.perf_counter()
+        for _ in range(128):
+            dec1.step()
+        torch.cuda.synchronize()
+        tdec = time.perf_counter() - tA
+        pf = min(times)
+        cfg1 = {"workload": "configs[1]: 4096-token prefill in one call (eager launches) + 128 graphed decode steps, B=1",
+                "prefill_ms": pf * 1e3, "prefill_tok_s": Tp / pf, "decode_tok_s": 128 / tdec,
+                "decode_ms_per_token": tdec / 128 * 1e3, "logits_finite": bool(torch.isfinite(lg.float()).all())}
+        del dec1, cache1
+
     kernels, cpu = None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = kernel_timings(device, T, args.window)
@@ -350,6 +388,8 @@ def main():
             out["hot_path_ms_per_step"] = sum(step_ms(v) for v in prefill_kernels.values())
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if cfg1 is not None:
+            out["cfg1_4k_prefill_decode"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg1.items()}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
