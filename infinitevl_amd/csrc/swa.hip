@@ -46,25 +46,68 @@ __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
   return r;
 }
 
-template <bool PACK, bool TR>
+// QG = 16-row query groups per wave (1: 64 rows per workgroup, decode / short calls; 2: 128 rows per workgroup).
+// With QG = 2 every K / V^T fragment read from LDS feeds two MFMAs: at QG = 1 the 4 waves of a workgroup pull
+// 128 KB through the 128 B/clk LDS port per 64-key tile (1024 clk) for 512 clk of MFMA work per SIMD.
+// single-instruction max helpers (a plain fmaxf on MFMA results draws a canonicalising v_max per operand)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// butterfly over the four 16-lane groups of a wave (the lanes that share a query row) on the gfx950 lane-swap
+// instructions: v_permlane16_swap exchanges odd rows of one operand with even rows of the other, v_permlane32_swap
+// the upper half with the lower half; with both operands = x the two results hold x and its partner.
+__device__ __forceinline__ float group_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float group_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <bool PACK, bool TR, int QG>
 __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SWA_LDS_BYTES];
+  constexpr int QT = SWA_QT * QG;      // query rows per workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int G = p.Hq / p.Hkv;
   // 1-D grid with an XCD-aware (bijective) remap: hardware block id i runs on XCD i % 8; logical ids are
   // ordered (b, split, kv-head, head-in-group, q-tile) so the workgroups that read the SAME K/V range are
   // consecutive and therefore land on the same XCD / L2 (they re-read each K/V tile up to 8 x n_qtiles times).
-  int lid;
+  const int heads_y = PACK ? p.Hkv : p.Hq;
+  int bx, rest;                      // q-tile, and (b * nsplit + split) * heads_y + head
   {
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int qn = nwg >> 3, rn = nwg & 7;
-    lid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    if (rn == 0 && qn % p.n_qtiles == 0) {
+      // every XCD owns whole (batch, split, head) rows.  Inside an XCD the workgroups are issued heaviest first
+      // (the work of a q-tile grows with its index: causal / window not yet full), so the long workgroups no
+      // longer form the tail.  When all of them are co-resident (<= 2 per CU) the upper half goes first in
+      // descending order and the lower half follows in ascending order: a heavy one shares its CU with a light one.
+      const int hx = qn / p.n_qtiles;                       // rows per XCD
+      const int r = slot / hx, half = (p.n_qtiles + 1) >> 1;
+      bx = qn > 64 ? p.n_qtiles - 1 - r : (r < half ? p.n_qtiles - 1 - r : r - half);
+      rest = xcd * hx + slot % hx;
+    } else {
+      const int lid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+      bx = lid % p.n_qtiles;
+      rest = lid / p.n_qtiles;
+    }
   }
-  const int heads_y = PACK ? p.Hkv : p.Hq;
-  const int bx = lid % p.n_qtiles;                       // q-tile
-  const int by = (lid / p.n_qtiles) % heads_y;           // q head (or kv head when PACK); heads of one group adjacent
-  const int bz = lid / (p.n_qtiles * heads_y);           // b * nsplit + split
+  const int by = rest % heads_y;                         // q head (or kv head when PACK); heads of one group adjacent
+  const int bz = rest / heads_y;                         // b * nsplit + split
   const int b = bz / p.nsplit, split = bz % p.nsplit;
   const int hk = PACK ? by : by / G;
 
@@ -77,19 +120,24 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 
   // ---- rows of this workgroup / wave / lane ----------------------------------------------------
   const int total_rows = PACK ? p.T * G : p.T;
-  const int tile_row0 = bx * SWA_QT;
-  const int row = tile_row0 + wave * 16 + l15;
-  const bool row_ok = row < total_rows;
-  const int t_row = PACK ? row / G : row;
-  const int hq = PACK ? hk * G + row % G : by;
-  const int hi = n_prev + t_row;
-  const int lo = p.W > 0 ? max(0, n_prev + t_row - p.W + 1) : 0;
+  const int tile_row0 = bx * QT;
+  int t_row[QG], hq[QG], hi[QG], lo[QG];
+  bool row_ok[QG];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const int row = tile_row0 + (wave * QG + qg) * 16 + l15;
+    row_ok[qg] = row < total_rows;
+    t_row[qg] = PACK ? row / G : row;
+    hq[qg] = PACK ? hk * G + row % G : by;
+    hi[qg] = n_prev + t_row[qg];
+    lo[qg] = p.W > 0 ? max(0, n_prev + t_row[qg] - p.W + 1) : 0;
+  }
 
   // band extremes over the rows of THIS wave (rows are consecutive; lo/hi are monotone in the row index)
   int w_lo_max, w_hi_min;
   {
-    const int wr0 = tile_row0 + wave * 16;
-    const int wr1 = min(wr0 + 15, total_rows - 1);
+    const int wr0 = tile_row0 + wave * 16 * QG;
+    const int wr1 = min(wr0 + 16 * QG - 1, total_rows - 1);
     const int t_first = PACK ? wr0 / G : wr0;
     const int t_last = PACK ? max(wr1, wr0) / G : max(wr1, wr0);
     w_hi_min = n_prev + t_first;
@@ -97,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   }
 
   // workgroup key-tile range
-  const int last_row = min(tile_row0 + SWA_QT, total_rows) - 1;
+  const int last_row = min(tile_row0 + QT, total_rows) - 1;
   const int t_min = PACK ? tile_row0 / G : tile_row0;
   const int t_max = PACK ? last_row / G : last_row;
   const int lo_min = p.W > 0 ? max(0, n_prev + t_min - p.W + 1) : 0;
@@ -107,20 +155,26 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   const int kt_end = min(kt1, kt_begin + per);
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane = query row, k-slots 8g..8g+7 of each 32-chunk ----
-  u32x4 qf[4];
-  {
-    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)t_row * p.q_st + (long long)hq * p.q_sh;
+  u32x4 qf[QG][4];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)t_row[qg] * p.q_st + (long long)hq[qg] * p.q_sh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (row_ok) qf[ks] = *(const u32x4*)(qp + 32 * ks + 8 * g);
-      else qf[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (row_ok[qg]) qf[qg][ks] = *(const u32x4*)(qp + 32 * ks + 8 * g);
+      else qf[qg][ks] = u32x4{0u, 0u, 0u, 0u};
     }
   }
 
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4 oacc[8];
+  float m_run[QG], l_run[QG];
+  f32x4 oacc[QG][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = -INFINITY;
+    l_run[qg] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oacc[qg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- staging: thread -> rows (tid>>4) + 16 i, 16-byte chunk tid&15 ------------------------------
   const int srow = tid >> 4, schunk = tid & 15;
@@ -132,11 +186,33 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   const bf16_t* vb_new = p.v_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
   const unsigned int kn_st32 = (unsigned int)p.kn_st;
   auto load_tile = [&](int kt) {
-    // branch-free: every row issues its two 16-byte loads (clamped address); a conditional load per row
-    // would serialise one memory round trip per row.  Only the last tile can hold rows >= S (zeroed).
+    const int j0 = kt * SWA_KT;
+    const int slot0 = s0 + j0;
+    if (j0 + SWA_KT <= n_ring && (slot0 + SWA_KT <= p.C || slot0 >= p.C)) {
+      // wave-uniform fast path (almost every tile of a full window): 64 consecutive ring slots, no wrap inside
+      const unsigned int off = (unsigned int)((slot0 >= p.C ? slot0 - p.C : slot0) + srow) * SWA_D;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kreg[i] = *(const u32x4*)(kb_ring + off + 16 * i * SWA_D);
+        vreg[i] = *(const u32x4*)(vb_ring + off + 16 * i * SWA_D);
+      }
+      return;
+    }
+    if (j0 >= n_ring && j0 + SWA_KT <= S) {
+      // wave-uniform fast path: 64 keys of this call
+      const unsigned int off = (unsigned int)(j0 - n_ring + srow) * kn_st32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kreg[i] = *(const u32x4*)(kb_new + off + 16 * i * kn_st32);
+        vreg[i] = *(const u32x4*)(vb_new + off + 16 * i * kn_st32);
+      }
+      return;
+    }
+    // generic tile (ring wrap, ring/new seam or tail).  Branch-free per row: every row issues its two 16-byte
+    // loads (clamped address); a conditional load per row would serialise one memory round trip per row.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = kt * SWA_KT + srow + 16 * i;
+      const int j = j0 + srow + 16 * i;
       const int jc = min(j, S - 1);
       const bool in_ring = jc < n_ring;
       int slot = s0 + jc;
@@ -147,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
       kreg[i] = *(const u32x4*)kp;
       vreg[i] = *(const u32x4*)vp;
     }
-    if (kt * SWA_KT + SWA_KT > S) {          // wave-uniform: tail tile
+    if (j0 + SWA_KT > S) {          // wave-uniform: tail tile, rows >= S are zeroed
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (kt * SWA_KT + srow + 16 * i >= S) {
+        if (j0 + srow + 16 * i >= S) {
           kreg[i] = u32x4{0u, 0u, 0u, 0u};
           vreg[i] = u32x4{0u, 0u, 0u, 0u};
         }
@@ -177,84 +253,86 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     __syncthreads();
     if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 1);
 
-    // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps; d-step outermost so that consecutive MFMAs go to four
+    // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps; d-step outermost so that consecutive MFMAs go to
     //      independent accumulators (no back-to-back dependent issue) -------------------------------------
-    f32x4 sacc[4];
+    f32x4 sacc[QG][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sacc[qg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const u32x4 kf = *(const u32x4*)(smem + (16 * mt + l15) * SWA_KSTRIDE + (4 * ks + g) * 16);
-        sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(kf), as_mfma(qf[ks]), sacc[mt], 0, 0, 0);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+          sacc[qg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(kf), as_mfma(qf[qg][ks]), sacc[qg][mt], 0, 0, 0);
       }
     }
     // next tile's global loads are issued behind the first MFMA batch (their address arithmetic no longer
     // delays it); they have the softmax + PV phases to land before store_tile of the next iteration
     if (kt + 1 < kt_end) load_tile(kt + 1);
     if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 2);
-    // ---- band mask + online softmax (lane-local row) ------------------------------------------
+    // ---- band mask + online softmax (lane-local rows) -----------------------------------------
     // Interior tiles (every key visible to every row of this wave) skip the per-element band test.
     const int jbase = kt * SWA_KT + 4 * g;
     const bool interior = kt * SWA_KT >= w_lo_max && kt * SWA_KT + SWA_KT - 1 <= w_hi_min;
-    float rmax = -INFINITY;
-    if (interior) {
+    u32x4 pf[QG][2];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+    for (int qg = 0; qg < QG; ++qg) {
+      // scores stay raw; the softmax scale is folded into the exponent: p = 2^(s*sc - m), m tracked in scaled units
+      if (!interior) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s = sacc[mt][r] * sc;
-          sacc[mt][r] = s;
-          rmax = fmaxf(rmax, s);
-        }
-    } else {
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = jbase + 16 * mt + r;
-          const bool vis = row_ok && j >= lo && j <= hi;
-          const float s = vis ? sacc[mt][r] * sc : -INFINITY;
-          sacc[mt][r] = s;
-          rmax = fmaxf(rmax, s);
-        }
-    }
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    const float m_new = fmaxf(m_run, rmax);
-    const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    float rsum = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[mt][r] - m_use);    // arguments <= 0: raw v_exp_f32
-        sacc[mt][r] = pv;
-        rsum += pv;
+          for (int r = 0; r < 4; ++r) {
+            const int j = jbase + 16 * mt + r;
+            const bool vis = row_ok[qg] && j >= lo[qg] && j <= hi[qg];
+            sacc[qg][mt][r] = vis ? sacc[qg][mt][r] : -INFINITY;
+          }
       }
-    rsum += __shfl_xor(rsum, 16, 64);
-    rsum += __shfl_xor(rsum, 32, 64);
-    if (__any(m_new > m_run)) {                          // some row's running max moved: rescale (exact)
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run = -inf -> 0
-      l_run = l_run * alpha + rsum;
+      float rmax = vmax3(sacc[qg][0][0], sacc[qg][0][1], sacc[qg][0][2]);
+      rmax = vmax3(rmax, sacc[qg][0][3], sacc[qg][1][0]);
+      rmax = vmax3(rmax, sacc[qg][1][1], sacc[qg][1][2]);
+      rmax = vmax3(rmax, sacc[qg][1][3], sacc[qg][2][0]);
+      rmax = vmax3(rmax, sacc[qg][2][1], sacc[qg][2][2]);
+      rmax = vmax3(rmax, sacc[qg][2][3], sacc[qg][3][0]);
+      rmax = vmax3(rmax, sacc[qg][3][1], sacc[qg][3][2]);
+      rmax = vmax2(rmax, sacc[qg][3][3]);
+      rmax = group_max(rmax) * sc;                             // sc > 0: max commutes with the scale
+      const float m_new = vmax2(m_run[qg], rmax);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      float rsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) oacc[i] *= alpha;
-    } else {
-      l_run += rsum;
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][mt][r], sc, -m_use));   // argument <= 0
+          sacc[qg][mt][r] = pv;
+          rsum += pv;
+        }
+      rsum = group_sum(rsum);
+      if (__any(m_new > m_run[qg])) {                        // some row's running max moved: rescale (exact)
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_use);      // m_run = -inf -> 0
+        l_run[qg] = l_run[qg] * alpha + rsum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) oacc[qg][i] *= alpha;
+      } else {
+        l_run[qg] += rsum;
+      }
+      m_run[qg] = m_new;
+      // P^T fragments (B operand): slots 8g+e <-> keys 32ks2+4g+e | 32ks2+16+4g+(e-4)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        pf[qg][ks2].x = pack2bf(sacc[qg][2 * ks2][0], sacc[qg][2 * ks2][1]);
+        pf[qg][ks2].y = pack2bf(sacc[qg][2 * ks2][2], sacc[qg][2 * ks2][3]);
+        pf[qg][ks2].z = pack2bf(sacc[qg][2 * ks2 + 1][0], sacc[qg][2 * ks2 + 1][1]);
+        pf[qg][ks2].w = pack2bf(sacc[qg][2 * ks2 + 1][2], sacc[qg][2 * ks2 + 1][3]);
+      }
     }
-    m_run = m_new;
 
     if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 3);
-    // ---- P^T fragments (B operand): slots 8g+e <-> keys 32ks2+4g+e | 32ks2+16+4g+(e-4) ---------
-    u32x4 pf[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-      pf[ks2].x = pack2bf(sacc[2 * ks2][0], sacc[2 * ks2][1]);
-      pf[ks2].y = pack2bf(sacc[2 * ks2][2], sacc[2 * ks2][3]);
-      pf[ks2].z = pack2bf(sacc[2 * ks2 + 1][0], sacc[2 * ks2 + 1][1]);
-      pf[ks2].w = pack2bf(sacc[2 * ks2 + 1][2], sacc[2 * ks2 + 1][3]);
-    }
     // ---- O^T += V^T P^T : 8 d sub-tiles x 2 key-steps ------------------------------------------
     const unsigned char* vbase = smem + SWA_LDS_K;
 #pragma unroll
@@ -286,32 +364,37 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
           vf = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                      (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
         }
-        oacc[mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(vf), as_mfma(pf[ks2]), oacc[mt2], 0, 0, 0);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+          oacc[qg][mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(vf), as_mfma(pf[qg][ks2]), oacc[qg][mt2], 0, 0, 0);
       }
     }
   }
 
   trace_stamp(p.trace, 40);
-  // ---- epilogue: lane owns row `row`, d = 16 mt2 + 4g + r ---------------------------------------
-  if (!row_ok) return;
-  if (p.nsplit == 1) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16_t* op = p.o + (((long long)b * p.T + t_row) * p.Hq + hq) * SWA_D + 4 * g;
+  // ---- epilogue: lane owns its rows, d = 16 mt2 + 4g + r ----------------------------------------
 #pragma unroll
-    for (int mt2 = 0; mt2 < 8; ++mt2) {
-      u32x2 w;
-      w.x = pack2bf(oacc[mt2][0] * inv, oacc[mt2][1] * inv);
-      w.y = pack2bf(oacc[mt2][2] * inv, oacc[mt2][3] * inv);
-      *(u32x2*)(op + 16 * mt2) = w;
-    }
-  } else {
-    const long long prow = (((long long)b * p.nsplit + split) * p.T + t_row) * p.Hq + hq;
-    float* po = p.part_o + prow * SWA_D + 4 * g;
+  for (int qg = 0; qg < QG; ++qg) {
+    if (!row_ok[qg]) continue;
+    if (p.nsplit == 1) {
+      const float inv = l_run[qg] > 0.f ? 1.0f / l_run[qg] : 0.f;
+      bf16_t* op = p.o + (((long long)b * p.T + t_row[qg]) * p.Hq + hq[qg]) * SWA_D + 4 * g;
 #pragma unroll
-    for (int mt2 = 0; mt2 < 8; ++mt2) *(f32x4*)(po + 16 * mt2) = oacc[mt2];
-    if (g == 0) {
-      p.part_ml[prow * 2] = m_run;
-      p.part_ml[prow * 2 + 1] = l_run;
+      for (int mt2 = 0; mt2 < 8; ++mt2) {
+        u32x2 w;
+        w.x = pack2bf(oacc[qg][mt2][0] * inv, oacc[qg][mt2][1] * inv);
+        w.y = pack2bf(oacc[qg][mt2][2] * inv, oacc[qg][mt2][3] * inv);
+        *(u32x2*)(op + 16 * mt2) = w;
+      }
+    } else {
+      const long long prow = (((long long)b * p.nsplit + split) * p.T + t_row[qg]) * p.Hq + hq[qg];
+      float* po = p.part_o + prow * SWA_D + 4 * g;
+#pragma unroll
+      for (int mt2 = 0; mt2 < 8; ++mt2) *(f32x4*)(po + 16 * mt2) = oacc[qg][mt2];
+      if (g == 0) {
+        p.part_ml[prow * 2] = m_run[qg];
+        p.part_ml[prow * 2 + 1] = l_run[qg];
+      }
     }
   }
 }
@@ -376,8 +459,22 @@ __global__ __launch_bounds__(256) void swa_cache_append_kernel(
   }
 }
 
+// 16-row query groups per wave.  128-row workgroups halve the LDS traffic per MFMA (1.4x per-tile efficiency) but
+// also halve the number of workgroups: they pay once a call still offers >= 4 workgroups per CU (B*T*Hq >= 128K rows);
+// below that the finer 64-row granularity balances the causal triangle better (measured: T=4096 118 vs 132 us).
+static int swa_qg(int B, int T, int Hq) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("IVL_SWA_QG");     // debug override: 1 or 2
+    force = e ? atoi(e) : 0;
+  }
+  if (force == 1 || force == 2) return force;
+  return (long long)B * T * Hq >= 131072 ? 2 : 1;
+}
+
 static int swa_base_nsplit(int B, int T, int Hq) {
-  const long long base = (long long)B * ((T + SWA_QT - 1) / SWA_QT) * Hq;
+  const int qt = SWA_QT * swa_qg(B, T, Hq);
+  const long long base = (long long)B * ((T + qt - 1) / qt) * Hq;
   long long ns = (512 + base - 1) / base;
   if (ns < 1) ns = 1;
   if (ns > SWA_MAX_SPLIT) ns = SWA_MAX_SPLIT;
@@ -419,7 +516,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   const bool pack = (long long)a->T * G <= SWA_QT && G <= 16;
   // worst-case number of key tiles a workgroup walks (n_prev unknown under graph replay -> capacity)
   const long long max_prev = (long long)a->cache_capacity + (a->T_new - a->T);
-  long long span = a->window > 0 ? (long long)a->window + SWA_QT : max_prev + a->T;
+  long long span = a->window > 0 ? (long long)a->window + 2 * SWA_QT : max_prev + a->T;
   if (span > max_prev + a->T) span = max_prev + a->T;
   const int max_tiles = (int)(span / SWA_KT) + 2;
   int nsplit = 1;
@@ -449,16 +546,20 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     p.part_ml = p.part_o + n_o;
   }
   const int rows = pack ? a->T * G : a->T;
-  p.n_qtiles = (rows + SWA_QT - 1) / SWA_QT;
+  const int qg = pack ? 1 : swa_qg(a->B, a->T, a->Hq);
+  p.n_qtiles = (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
   hipStream_t st = (hipStream_t)stream;
   const bool tr = swa_use_tr();
   if (pack) {
-    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((swa_fwd_kernel<true, false>), grid, dim3(256), 0, st, p);
+    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<true, true, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((swa_fwd_kernel<true, false, 1>), grid, dim3(256), 0, st, p);
+  } else if (qg == 2) {
+    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((swa_fwd_kernel<false, false, 2>), grid, dim3(256), 0, st, p);
   } else {
-    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((swa_fwd_kernel<false, false>), grid, dim3(256), 0, st, p);
+    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((swa_fwd_kernel<false, false, 1>), grid, dim3(256), 0, st, p);
   }
   int rc = check_launch("ivl_swa_fwd");
   if (rc != IVL_OK) return rc;

@@ -241,7 +241,8 @@ def _band_counts(n_prev, T, W):
 
 
 @pytest.mark.parametrize("W,seen,T", [(8, 0, 5), (8, 0, 19), (8, 7, 6), (8, 40, 1), (96, 250, 70), (4096, 0, 300),
-                                      (4096, 4000, 256), (4096, 9000, 256), (4096, 9000, 1), (4096, 4095, 64)])
+                                      (4096, 4000, 256), (4096, 9000, 256), (4096, 9000, 1), (4096, 4095, 64),
+                                      (4096, 0, 8192), (1024, 5000, 8192)])   # last two: 128-row workgroups
 def test_swa_band_indices_bit_exact(W, seen, T):
     """The integer contract: the set of keys each query row sees."""
     from infinitevl_amd import ops
@@ -261,6 +262,24 @@ def test_swa_band_indices_bit_exact(W, seen, T):
         counts = torch.round(got * n_vis).to(torch.int64)
         for h in (0, 7, 15):
             assert np.array_equal(counts[:, h].numpy(), expect), (which, h)
+
+
+def test_swa_128_row_workgroups_equal_64_row_workgroups():
+    """Large calls (B*T*Hq >= 128K rows) run the variant with two 16-row query groups per wave; a row's tiles
+    and their order are the same in both variants, so a batched call must equal the per-sequence calls bit for bit."""
+    from infinitevl_amd import ops
+    B, T, Hq, Hkv, d, W = 2, 4096, 16, 2, 128, 1024
+    C = W - 1
+    torch.manual_seed(11)
+    kc, vc = bf(torch.randn(B, Hkv, C, d)).to(DEV), bf(torch.randn(B, Hkv, C, d)).to(DEV)
+    pos_dev = torch.full((1,), 3000, dtype=torch.int64, device=DEV)
+    q, kn, vn = (bf(torch.randn(B, T, h, d)).to(DEV) for h in (Hq, Hkv, Hkv))
+    o_big = ops.swa_forward(q, kn, vn, window=W, scaling=d ** -0.5, k_cache=kc, v_cache=vc, pos_dev=pos_dev)
+    for b in range(B):
+        o_one = ops.swa_forward(q[b:b + 1], kn[b:b + 1], vn[b:b + 1], window=W, scaling=d ** -0.5,
+                                k_cache=kc[b:b + 1].contiguous(), v_cache=vc[b:b + 1].contiguous(), pos_dev=pos_dev)
+        assert torch.equal(o_big[b:b + 1], o_one), b
+    assert torch.isfinite(o_big.float()).all()
 
 
 def test_swa_ring_path_equals_concatenated_path():
