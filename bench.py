@@ -166,6 +166,32 @@ def kernel_timings(device, chunk, window, only=None):
     qd, kd1, vd1 = rn(B, 1, Hq, d), rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
     add("swa_decode", lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
                                               pos_dev=pos_dev), 100, 9, "hbm", 1024.0 * window)
+    # decode-step projections (M = 1 weight streams; outside SURVEY.md section 8's rows, listed for the decode leg)
+    for nm, N_, K_, per in (("gdn in-proj", 12320, 2048, 27), ("mlp gate|up", 22016, 2048, 36),
+                            ("mlp down", 2048, 11008, 36), ("gdn o_proj", 2048, 4096, 27), ("lm_head", 151936, 2048, 1)):
+        w_, x_ = rn(N_, K_), rn(1, 1, K_)
+        add(f"decode linear {nm} [{N_}x{K_}]", lambda w_=w_, x_=x_: ops.linear(x_, w_), 50, 0, "hbm",
+            2.0 * N_ * K_ + 2.0 * (N_ + K_))
+        res_key = f"decode linear {nm} [{N_}x{K_}]"
+        if res_key in res:
+            res[res_key]["launches_per_decode_token"] = per
+        del w_, x_
+    # batched streams (8 sequences per GPU in one call): the same kernels with 8x the work per launch -- shows that
+    # the low fractions at B=1 come from the size of a 256-token step, not from the kernels
+    Bb = 8
+    qb, kb_, vb_ = rn(Bb, T, H, K), rn(Bb, T, H, K), rn(Bb, T, H, V)
+    betab = torch.rand(Bb, T, H, device=device, generator=g_).to(torch.bfloat16)
+    gb_ = torch.nn.functional.logsigmoid(torch.randn(Bb, T, H, device=device, generator=g_))
+    stateb = torch.randn(Bb, H, K, V, device=device, generator=g_).to(torch.bfloat16)
+    add("gdn_chunk@B=8", lambda: ops.chunk_gated_delta_rule(
+        qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb),
+        10, 0, "hbm", Bb * (24672.0 * T + 2 * H * K * V * 4))
+    kcb, vcb = rn(Bb, Hkv, C, d), rn(Bb, Hkv, C, d)
+    qsb, knb, vnb = rn(Bb, T, Hq, d), rn(Bb, T, Hkv, d), rn(Bb, T, Hkv, d)
+    add("swa_prefill@B=8", lambda: ops.swa_forward(qsb, knb, vnb, window=window, scaling=d ** -0.5, k_cache=kcb,
+                                                   v_cache=vcb, pos_dev=pos_dev), 10, 0, "mfma",
+        Bb * 4.0 * Hq * d * window * T)
+    del qb, kb_, vb_, kcb, vcb, qsb, knb, vnb
     # throughput-regime shapes (one-shot 4096-token prefill, BASELINE.json configs[1]); not part of the step
     TL = 4096
     qL, kL, vL, gL, bL = gdn_inputs(TL)

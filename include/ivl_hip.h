@@ -197,6 +197,18 @@ int ivl_add_rmsnorm_fwd(const void* x, const void* residual, const void* weight,
 /* SwiGLU gate over a fused gate|up projection: y[r,i] = bf16(bf16(silu(gu[r,i])) * gu[r,I+i]) (std:945). */
 int ivl_silu_mul_fwd(const void* gate_up, void* y, int64_t rows, int I, void* stream);
 
+/* nn.Linear for the single-token decode step (M <= 4 rows): y[M,N] = bf16(x[M,K] W[N,K]^T + bias[N]).
+ * Replaces the q/k/v/o, GDN in/out, MLP and tied lm_head projections (std:1047-1054, 1215-1240, 945, 2091-2092)
+ * when q_len == 1: a pure weight stream bounded by HBM.  x,W,bias,y bf16, row-major contiguous; fp32 accumulation;
+ * bias may be NULL.  K % 8 == 0.  IVL_ERR_UNSUPPORTED for M > 4 (callers use a GEMM there). */
+int ivl_linear_small_m_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
+
+/* SwiGLU MLP head of a decode step (std:945: act_fn(gate_proj(x)) * up_proj(x)), fused gate|up weight [2I,K]:
+ *   y[M,I] = bf16( bf16(silu(bf16(x Wg^T))) * bf16(x Wu^T) ),  Wg = w_gate_up[:I], Wu = w_gate_up[I:]
+ * = ivl_linear_small_m_fwd on the fused weight followed by ivl_silu_mul_fwd, bit for bit.  bias [2I] or NULL. */
+int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, const void* bias, void* y, int M, int I, int K,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

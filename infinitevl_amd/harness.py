@@ -110,7 +110,7 @@ class InfiniteVLTextMLP(nn.Module):
     def forward(self, x):
         if (self._fused_w is not None and x.is_cuda and x.dtype == torch.bfloat16
                 and self.gate_proj.weight.data_ptr() == self._fused_w.data_ptr()):
-            return self.down_proj(ops.silu_mul(F.linear(x, self._fused_w)))
+            return ops.linear(ops.linear_swiglu(x, self._fused_w), self.down_proj.weight)
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
@@ -218,7 +218,7 @@ class InfiniteVLTextStack(nn.Module):
             _, h = self.norm.add_and_norm(pend, resid)
         logits = None
         if logits_to_keep:
-            logits = F.linear(h[:, -logits_to_keep:, :], self.embed_tokens.weight)  # tied lm_head (std:2091-2092)
+            logits = ops.linear(h[:, -logits_to_keep:, :], self.embed_tokens.weight)  # tied lm_head (std:2091-2092)
         return h, logits
 
 

@@ -106,7 +106,7 @@ class InfiniteVLSelfAttention(nn.Module):
         # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
         if self._fused_ok(hidden_states):
             nq, nkv = self.num_heads * self.head_dim, self.num_key_value_heads * self.head_dim
-            qkv = torch.nn.functional.linear(hidden_states, self._fused_w, self._fused_b)     # [B,T,nq+2nkv]
+            qkv = ops.linear(hidden_states, self._fused_w, self._fused_b)                     # [B,T,nq+2nkv]
             q = qkv[..., :nq].unflatten(-1, (self.num_heads, self.head_dim))
             k = qkv[..., nq:nq + nkv].unflatten(-1, (self.num_key_value_heads, self.head_dim))
             v = qkv[..., nq + nkv:].unflatten(-1, (self.num_key_value_heads, self.head_dim))
@@ -129,7 +129,7 @@ class InfiniteVLSelfAttention(nn.Module):
             attn, _ = ops.swa_attention_interface(self, q.transpose(1, 2), fk, fv, None, scaling=self.scaling,
                                                   sliding_window=self.sliding_window)
         attn = attn.reshape(bsz, q_len, -1)
-        return self.o_proj(attn), None
+        return ops.linear(attn, self.o_proj.weight, self.o_proj.bias), None
 
 
 class GatedDeltaNet(nn.Module):
@@ -231,7 +231,7 @@ class GatedDeltaNet(nn.Module):
         H, K, V = self.num_heads, self.head_dim, self.head_v_dim
         Dq, Dk, Dv = H * K, self.key_dim, self.value_dim
         cq, ck, cv, cg, ca, cb = self._fused_cols
-        proj = torch.nn.functional.linear(hidden_states, self._fused_w)               # [B,T,ld]
+        proj = ops.linear(hidden_states, self._fused_w)                               # [B,T,ld]
         ld = proj.shape[-1]
         prev = (None, None, None)
         h0 = None
@@ -257,7 +257,7 @@ class GatedDeltaNet(nn.Module):
         w = self.o_norm.weight
         o = ops.rmsnorm_swish_gate_strided(o, proj[..., cg:], ld, w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16),
                                            self.norm_eps)
-        return self.o_proj(o.reshape(B, T, -1)), None
+        return ops.linear(o.reshape(B, T, -1), self.o_proj.weight, self.o_proj.bias), None
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 past_key_values=None, cache_position: Optional[torch.LongTensor] = None, **kwargs):

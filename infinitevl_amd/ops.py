@@ -307,6 +307,39 @@ def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear forward.  A single-token decode step (<= 4 rows) is a pure weight stream and goes through
+    ivl_linear_small_m_fwd; longer calls are stock library GEMMs (hipBLASLt / rocBLAS through torch), which
+    SURVEY.md 8(d) keeps outside the hot path."""
+    K = weight.shape[-1]
+    rows = x.numel() // K if K else 0
+    if (x.is_cuda and 1 <= rows <= 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and weight.dim() == 2 and weight.is_contiguous() and K % 8 == 0
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))):
+        xc = x if x.is_contiguous() else x.contiguous()
+        N = weight.shape[0]
+        y = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.load().ivl_linear_small_m_fwd(_p(xc), _p(weight), _p(bias) if bias is not None else None,
+                                                      _p(y), rows, N, K, _stream(x)))
+        return y
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def linear_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor) -> torch.Tensor:
+    """silu(gate_proj(x)) * up_proj(x) with the fused gate|up weight [2I, K] (std:945).  Decode steps (<= 4 rows)
+    apply the gate in the epilogue of the weight-stream kernel; longer calls are a library GEMM + silu_mul."""
+    K = w_gate_up.shape[-1]
+    I = w_gate_up.shape[0] // 2
+    rows = x.numel() // K
+    if (x.is_cuda and 1 <= rows <= 4 and x.dtype == torch.bfloat16 and w_gate_up.dtype == torch.bfloat16
+            and w_gate_up.is_contiguous() and K % 8 == 0):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty(*x.shape[:-1], I, dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.load().ivl_linear_swiglu_small_m_fwd(_p(xc), _p(w_gate_up), None, _p(y), rows, I, K, _stream(x)))
+        return y
+    return silu_mul(linear(x, w_gate_up))
+
+
 def apply_mrope_strided_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mrope_section):
     """M-RoPE in place on q [B,T,Hq,d] / k [B,T,Hkv,d] VIEWS into a fused qkv projection (row = token)."""
     _need_gpu(q, k, cos, sin)

@@ -59,6 +59,8 @@ def test_argument_validation_returns_codes(lib):
     assert lib.ivl_swa_fwd(ctypes.byref(a), None) == _lib.IVL_ERR_UNSUPPORTED   # head_dim != 128
     a.d, a.Hq = 128, 3
     assert lib.ivl_swa_fwd(ctypes.byref(a), None) == _lib.IVL_ERR_INVALID_ARG   # Hq % Hkv
+    assert lib.ivl_linear_small_m_fwd(one, one, None, one, 5, 16, 64, None) == _lib.IVL_ERR_UNSUPPORTED   # M > 4
+    assert lib.ivl_linear_small_m_fwd(one, one, None, one, 1, 16, 60, None) == _lib.IVL_ERR_INVALID_ARG   # K % 8
     with pytest.raises(ValueError):
         _lib.check(_lib.IVL_ERR_INVALID_ARG)
     with pytest.raises(_lib.IvlError):
