@@ -197,6 +197,17 @@ int ivl_add_rmsnorm_fwd(const void* x, const void* residual, const void* weight,
 /* SwiGLU gate over a fused gate|up projection: y[r,i] = bf16(bf16(silu(gu[r,i])) * gu[r,I+i]) (std:945). */
 int ivl_silu_mul_fwd(const void* gate_up, void* y, int64_t rows, int I, void* stream);
 
+/* Gated DeltaNet mixer core for ONE new token per sequence (GatedDeltaNet.forward, std:1215-1347, q_len == 1):
+ * = ivl_gdn_prologue_fwd + ivl_gdn_recurrent_fwd(use_qk_l2norm=1) + ivl_rmsnorm_swish_gate_strided_fwd in one launch,
+ * same rounding points.  proj [B, ld] bf16 is the fused projection row (columns col_q|col_k: H*128 each, col_v|col_g:
+ * H*256 each, col_a|col_b: H each); conv weights [D,4] bf16; conv states [B,D,4] bf16 and the recurrent state
+ * [B,H,128,256] (IVL_F32 / IVL_BF16) are updated IN PLACE; y [B, H*256] bf16 is the gated-norm output (o_proj input). */
+int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_g, int col_a,
+                            int col_b, const void* conv_wq, const void* conv_wk, const void* conv_wv,
+                            void* conv_state_q, void* conv_state_k, void* conv_state_v, const float* A_log,
+                            const float* dt_bias, const void* norm_weight, float eps, void* state, int state_dtype,
+                            void* y, int B, int H, int K, int V, float scale, void* stream);
+
 /* nn.Linear for the single-token decode step (M <= 4 rows): y[M,N] = bf16(x[M,K] W[N,K]^T + bias[N]).
  * Replaces the q/k/v/o, GDN in/out, MLP and tied lm_head projections (std:1047-1054, 1215-1240, 945, 2091-2092)
  * when q_len == 1: a pure weight stream bounded by HBM.  x,W,bias,y bf16, row-major contiguous; fp32 accumulation;

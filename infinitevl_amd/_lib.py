@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "ivl_swa_workspace_bytes", "ivl_swa_fwd", "ivl_swa_cache_append", "ivl_counter_add",
     "ivl_gdn_prologue_fwd", "ivl_rmsnorm_swish_gate_strided_fwd", "ivl_mrope_strided_fwd",
     "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd", "ivl_linear_small_m_fwd",
-    "ivl_linear_swiglu_small_m_fwd",
+    "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd",
 )
 
 
@@ -101,6 +101,9 @@ def load() -> ctypes.CDLL:
     lib.ivl_silu_mul_fwd.argtypes = [vp, vp, i64, i, vp]
     lib.ivl_linear_small_m_fwd.restype = i
     lib.ivl_linear_small_m_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.ivl_gdn_decode_step_fwd.restype = i
+    lib.ivl_gdn_decode_step_fwd.argtypes = [vp, i64, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, i,
+                                            vp, i, i, i, i, f, vp]
     lib.ivl_linear_swiglu_small_m_fwd.restype = i
     lib.ivl_linear_swiglu_small_m_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     _lib = lib

@@ -243,6 +243,18 @@ class GatedDeltaNet(nn.Module):
         else:
             outs = (None, None, None)
         A32, dt32 = self._gate_params32()
+        w = self.o_norm.weight
+        w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        if (T == 1 and layer is not None and prev[0] is not None and h0 is not None and Dk == Dq
+                and h0.data_ptr() == layer.recurrent_state.data_ptr() and K == 128 and V == 256):
+            # decode step: convs + gates + delta rule + gated norm in ONE launch, cache tensors updated in place
+            o = ops.gdn_decode_step(proj, (cq, ck, cv, cg, ca, cb),
+                                    (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight), outs, A32, dt32,
+                                    w, self.norm_eps, layer.recurrent_state, H, K, V, K ** -0.5)
+            past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
+                                   recurrent_state=layer.recurrent_state,
+                                   cache_kwargs={"op": "set", "delta_len": T, "cache_position": cache_position})
+            return ops.linear(o, self.o_proj.weight, self.o_proj.bias), None
         q, k, v, g, beta = ops.gdn_prologue(
             proj, (cq, ck, cv, ca, cb), (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight),
             prev, outs, A32, dt32, H, Dq, Dk, Dv)
@@ -254,9 +266,7 @@ class GatedDeltaNet(nn.Module):
             past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
                                    recurrent_state=layer.recurrent_state,
                                    cache_kwargs={"op": "set", "delta_len": T, "cache_position": cache_position})
-        w = self.o_norm.weight
-        o = ops.rmsnorm_swish_gate_strided(o, proj[..., cg:], ld, w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16),
-                                           self.norm_eps)
+        o = ops.rmsnorm_swish_gate_strided(o, proj[..., cg:], ld, w, self.norm_eps)
         return ops.linear(o.reshape(B, T, -1), self.o_proj.weight, self.o_proj.bias), None
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,

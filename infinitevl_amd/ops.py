@@ -270,6 +270,24 @@ def gdn_prologue(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv_st
     return q, k, v, g, beta
 
 
+def gdn_decode_step(proj: torch.Tensor, cols, conv_weights, conv_states, A_log32, dt_bias32, norm_weight, eps: float,
+                    state: torch.Tensor, H: int, K: int, V: int, scale: float) -> torch.Tensor:
+    """One new token per sequence through the GDN mixer core in ONE launch (convs + gates + delta rule + gated
+    norm).  proj [B,1,ld] bf16; cols = (col_q, col_k, col_v, col_g, col_a, col_b); conv_states 3 x [B,D,4] bf16 and
+    state [B,H,K,V] are updated in place.  Returns y [B,1,H*V] bf16 (the o_proj input)."""
+    _need_gpu(proj, state)
+    B, T, ld = proj.shape
+    assert T == 1 and proj.is_contiguous() and proj.dtype == torch.bfloat16 and state.is_contiguous()
+    y = torch.empty(B, 1, H * V, dtype=torch.bfloat16, device=proj.device)
+    wq, wk, wv = conv_weights
+    sq, sk, sv = conv_states
+    _lib.check(_lib.load().ivl_gdn_decode_step_fwd(
+        _p(proj), ld, cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], _p(wq), _p(wk), _p(wv), _p(sq), _p(sk), _p(sv),
+        _p(A_log32), _p(dt_bias32), _p(norm_weight), float(eps), _p(state), _DT_CODE[state.dtype], _p(y), B, H, K, V,
+        float(scale), _stream(proj)))
+    return y
+
+
 def rmsnorm_swish_gate_strided(x: torch.Tensor, gate_base: torch.Tensor, gate_ld: int, weight: torch.Tensor,
                                eps: float) -> torch.Tensor:
     """Gated RMSNorm with the gate read in place from a fused projection buffer.  x [B,T,H,256] bf16

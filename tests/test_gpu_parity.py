@@ -754,3 +754,40 @@ def test_decode_step_uses_weight_stream_and_matches_gemm_path():
     finally:
         ops.linear = real_linear
     assert rms_rel(outs[1][0], outs[0][0]) < 1e-2 and rms_rel(outs[1][1], outs[0][1]) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,state_dtype", [(1, 16, torch.bfloat16), (2, 3, torch.float32), (3, 2, torch.bfloat16)])
+def test_gdn_decode_step_equals_three_kernel_sequence(B, H, state_dtype):
+    """ivl_gdn_decode_step_fwd == ivl_gdn_prologue_fwd -> ivl_gdn_recurrent_fwd -> ivl_rmsnorm_swish_gate_strided_fwd
+    on the same fused projection row: conv states bit for bit (pure data movement), outputs / recurrent state to
+    fp32 summation order (the reductions are partitioned differently)."""
+    from infinitevl_amd import ops
+    K, V = 128, 256
+    Dq, Dv = H * K, H * V
+    cols = (0, Dq, 2 * Dq, 2 * Dq + Dv, 2 * Dq + 2 * Dv, 2 * Dq + 2 * Dv + H)      # q k v g a b
+    ld = cols[5] + H
+    ld += (-ld) % 8
+    torch.manual_seed(B * 100 + H)
+    state0 = bf(torch.randn(B, H, K, V)).to(DEV, state_dtype)
+    conv0 = [bf(torch.randn(B, D, 4)).to(DEV) for D in (Dq, Dq, Dv)]
+    cw = [bf(torch.randn(D, 1, 4) * 0.5).to(DEV) for D in (Dq, Dq, Dv)]
+    A32, dt32 = torch.randn(H).to(DEV), torch.randn(H).to(DEV)
+    wn = bf(torch.randn(V)).to(DEV)
+    for step in range(3):
+        proj = bf(torch.randn(B, 1, ld)).to(DEV)
+        if step == 0:
+            st_a, st_b = state0.clone(), state0.clone()
+            ca, cb = [c.clone() for c in conv0], [c.clone() for c in conv0]
+        # (a) three kernels
+        q, k, v, g, beta = ops.gdn_prologue(proj, (cols[0], cols[1], cols[2], cols[4], cols[5]), cw, ca, ca, A32, dt32,
+                                            H, Dq, Dq, Dv)
+        o, _ = ops.fused_recurrent_gated_delta_rule(q.view(B, 1, H, K), k.view(B, 1, H, K), v.view(B, 1, H, V), g, beta,
+                                                    initial_state=st_a, use_qk_l2norm_in_kernel=True, final_state_out=st_a)
+        y_a = ops.rmsnorm_swish_gate_strided(o, proj[..., cols[3]:], ld, wn, 1e-5).reshape(B, 1, Dv)
+        # (b) one launch
+        y_b = ops.gdn_decode_step(proj, cols, cw, cb, A32, dt32, wn, 1e-5, st_b, H, K, V, K ** -0.5)
+        for x_a, x_b in zip(ca, cb):
+            assert torch.equal(x_a, x_b), step
+        assert rms_rel(y_a.float().cpu(), y_b.float().cpu()) < 3e-3, step
+        assert rms_rel(st_a.float().cpu(), st_b.float().cpu()) < (3e-3 if state_dtype == torch.bfloat16 else 1e-5), step
+    assert torch.isfinite(y_b.float()).all()
