@@ -216,16 +216,22 @@ def pmc_traffic(kernel_name, chunk, window):
     if not files:
         return None
     k = json.load(open(files[-1]))["kernels"]
-    parts = {
-        "gdn_chunk(prepare+scan)": ["ivl::gdn_chunk_prepare_kernel@grid16384", "ivl::gdn_chunk_scan_kernel@grid32768"],
-        "swa_prefill": ["ivl::swa_fwd_kernel<false, true>@grid131072", "ivl::swa_combine_kernel<8>@grid262144"],
-        "gdn_prologue(3 convs + gates)": ["ivl::gdn_prologue_kernel@grid36864"],
-        "add_rmsnorm(decoder layer)": ["ivl::add_rmsnorm_kernel@grid65536"],
-        "rmsnorm_swish_gate": ["ivl::rmsnorm_gate_strided_kernel@grid131072"],
-        "gdn_recurrent(decode)": ["ivl::gdn_recurrent_kernel@grid32768"],
+    want = {
+        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel", 16384), ("ivl::gdn_chunk_scan_kernel", 32768)],
+        "swa_prefill": [("ivl::swa_fwd_kernel<false, true", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
+        "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 36864)],
+        "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
+        "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],
+        "gdn_recurrent(decode)": [("ivl::gdn_recurrent_kernel", 32768)],
     }.get(kernel_name)
-    if not parts or any(p_ not in k for p_ in parts):
+    if not want:
         return None
+    parts = []
+    for base, grid in want:          # kernel names carry template arguments: match on the prefix and the grid size
+        hit = [n for n in k if n.startswith(base) and n.endswith(f"@grid{grid}")]
+        if len(hit) != 1:
+            return None
+        parts.append(hit[0])
     return {"hbm_bytes": sum(k[p_]["hbm_bytes"] for p_ in parts), "source": os.path.basename(files[-1]),
             "launches": parts}
 
