@@ -163,6 +163,11 @@ def kernel_timings(device, chunk, window, only=None):
     add("gdn_recurrent(decode)", lambda: ops.fused_recurrent_gated_delta_rule(
         q1, k1, v1, g1, b1, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
         100, 27, "hbm", 24672.0 + 2 * H * K * V * 2)
+    proj1 = rn(B, 1, ld)
+    cols6 = (cols[0], cols[1], cols[2], Dq + Dk + Dv, cols[3], cols[4])
+    add("gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)", lambda: ops.gdn_decode_step(
+        proj1, cols6, cw, cs, A32, dt32, wn, 1e-5, state, H, K, V, K ** -0.5), 100, 0, "hbm",
+        2.0 * ld + 2 * H * K * V * 2 + 2.0 * H * V)
     qd, kd1, vd1 = rn(B, 1, Hq, d), rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
     add("swa_decode", lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
                                               pos_dev=pos_dev), 100, 9, "hbm", 1024.0 * window)
