@@ -182,6 +182,18 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         self.cumulative_length = 0
         self._pos_dev.zero_()
 
+    # ---- state hand-off (sequence-parallel prefill) ------------------------------------
+    def carried_tensors(self):
+        """Device tensors that fully define what the NEXT tokens of the sequence need from this layer: the ring
+        (last W-1 post-RoPE keys / values in slot order) and its position counter."""
+        return [t for t in (self._buf_keys, self._buf_values, self._pos_dev) if t is not None]
+
+    def import_carried(self, seen_tokens: int) -> None:
+        """Host-side counters after carried_tensors() were overwritten with the state of a sequence prefix of
+        `seen_tokens` tokens (the device counter arrived with the tensors)."""
+        self.size = int(min(self.capacity, seen_tokens))
+        self.cumulative_length = int(seen_tokens)
+
     def clone(self) -> "StaticSlidingWindowLayerPrealloc":
         """Deep copy (what the demo's clone_inference_cache does, demo:123-146)."""
         new = copy.copy(self)
@@ -318,6 +330,16 @@ class StaticLinearLayerPrealloc(_HFLayer):
     def reset(self) -> None:
         self.seq_len = 0
         self.start = False
+
+    # ---- state hand-off (sequence-parallel prefill) ------------------------------------
+    def carried_tensors(self):
+        """conv states [B,D,4] x3 + recurrent state [B,H,K,V]: everything the next tokens need from this layer."""
+        return [t for t in (self.conv_state_q, self.conv_state_k, self.conv_state_v, self.recurrent_state)
+                if t is not None]
+
+    def import_carried(self, seen_tokens: int) -> None:
+        self.seq_len = int(seen_tokens)
+        self.start = True            # the tensors hold a real prefix state: never take the first-call shortcut (Q4)
 
     def clone(self) -> "StaticLinearLayerPrealloc":
         new = copy.copy(self)

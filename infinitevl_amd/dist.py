@@ -3,11 +3,18 @@ sharded over ranks (one process per GPU, weights replicated, all recurrent state
 ONLY exchange is one all-gather of the last-position logits [B_local, vocab] over RCCL/xGMI at the
 very end -- latency-bound (~300 KB per rank), no per-layer collective, no ring all-reduce.
 
+sequence_parallel_prefill() is the one extension beyond the reference: ONE long
+sequence is cut into `world` consecutive segments; rank r runs the whole layer stack on segment r, and for every
+decoder layer receives the layer's carried state (GDN: conv + recurrent state, ~1 MiB; SWA: the W-1 key/value ring,
+<= 8.4 MB) from rank r-1 right before its mixer and forwards its own to rank r+1 right after it -- point-to-point
+over xGMI, no collective.  Rank r starts layer i as soon as rank r-1 has finished layer i, so the ranks form a
+wavefront over (segment, layer) and a prefill of S segments x L layers takes (S + L - 1) layer-times instead of S*L.
+
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2)."""
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -76,3 +83,73 @@ def gather_last_logits(logits_local: torch.Tensor, counts: List[int]) -> torch.T
     dist.all_gather_into_tensor(out, padded.contiguous())
     out = out.view(world, bmax, V)
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sequence-parallel prefill: per-layer state hand-off between consecutive ranks
+# ---------------------------------------------------------------------------------------------------------
+def _p2p_stage_through_host(t: torch.Tensor) -> bool:
+    """RCCL moves device tensors directly (xGMI peer-to-peer); gloo's send/recv take host tensors only."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def send_tensors(tensors: Sequence[torch.Tensor], dst: int) -> None:
+    for t in tensors:
+        dist.send(t.cpu() if _p2p_stage_through_host(t) else t, dst)
+
+
+def recv_tensors_(tensors: Sequence[torch.Tensor], src: int) -> None:
+    """Receive IN PLACE (tensor addresses stay: a captured hipGraph over the cache remains valid)."""
+    for t in tensors:
+        if _p2p_stage_through_host(t):
+            buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            dist.recv(buf, src)
+            t.copy_(buf)
+        else:
+            dist.recv(t, src)
+
+
+def segment_bounds(total_tokens: int, rank: int, world: int, multiple: int = 64) -> Tuple[int, int]:
+    """[first, last) token range of segment `rank`: equal segments rounded up to `multiple` tokens (the GDN chunk
+    length, so that a segment boundary is a chunk boundary); trailing ranks may get a short or empty segment."""
+    if total_tokens < 0 or world <= 0 or not (0 <= rank < world) or multiple <= 0:
+        raise ValueError(f"bad segment request: tokens={total_tokens} rank={rank} world={world}")
+    per = -(-total_tokens // world)
+    per = -(-per // multiple) * multiple
+    first = min(rank * per, total_tokens)
+    return first, min(first + per, total_tokens)
+
+
+def sequence_parallel_prefill(model: Callable, inputs_embeds: torch.Tensor, cache, first_token: int,
+                              rank: Optional[int] = None, world: Optional[int] = None, logits_to_keep: int = 0):
+    """Run `model` (an InfiniteVLTextStack, or anything with its forward(..., layer_hooks=) contract) on THIS rank's
+    segment `inputs_embeds` [B, T_r, hidden] of one long sequence whose first token has absolute index `first_token`.
+    `cache` is this rank's own pre-allocated cache; its layers are overwritten, layer by layer, with the state rank
+    r-1 reached at the end of its segment, and handed on after this rank's segment.  Ranks with an empty segment
+    (T_r == 0) just relay.  Returns model's (hidden, logits) for the local segment (None, None when empty).
+    After the call the LAST rank's cache holds the state of the whole sequence."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    B, T = inputs_embeds.shape[0], inputs_embeds.shape[1]
+    has_prev, has_next = rank > 0 and first_token > 0, rank + 1 < world
+
+    def before(i: int) -> None:
+        if has_prev:
+            layer = cache.layers[i]
+            recv_tensors_(layer.carried_tensors(), rank - 1)
+            layer.import_carried(first_token)
+
+    def after(i: int) -> None:
+        if has_next:
+            send_tensors(cache.layers[i].carried_tensors(), rank + 1)
+
+    if T == 0:                                   # nothing to compute: pass every layer's state through
+        for i in range(len(cache.layers)):
+            before(i)
+            after(i)
+        return None, None
+    pos = torch.arange(first_token, first_token + T, device=inputs_embeds.device)[None, None, :].expand(3, B, T)
+    return model(inputs_embeds=inputs_embeds, position_ids=pos.contiguous(), past_key_values=cache,
+                 logits_to_keep=logits_to_keep, layer_hooks=(before, after))

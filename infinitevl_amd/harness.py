@@ -158,8 +158,16 @@ class InfiniteVLTextStack(nn.Module):
         offline).  Works in place on whatever device/dtype the parameters live on."""
         dev = next(self.parameters()).device
         gen = torch.Generator(device=dev).manual_seed(seed)
+        import math
         for name, p_ in self.named_parameters():
-            if name.endswith("A_log") or name.endswith("dt_bias"):
+            if name.endswith("A_log"):              # same distributions as the constructor (std:1177-1190), but drawn
+                a = torch.rand(p_.shape, generator=gen, device=dev, dtype=torch.float32) * 16   # from THIS generator so
+                p_.copy_(torch.log(a.clamp_min(1e-3)))                                      # replicas agree
+                continue
+            if name.endswith("dt_bias"):
+                u = torch.rand(p_.shape, generator=gen, device=dev, dtype=torch.float32)
+                dt = torch.exp(u * (math.log(0.1) - math.log(0.001)) + math.log(0.001)).clamp_min(1e-4)
+                p_.copy_(dt + torch.log(-torch.expm1(-dt)))
                 continue
             if "layernorm" in name or name.endswith("norm.weight"):
                 p_.fill_(1.0)
@@ -186,8 +194,10 @@ class InfiniteVLTextStack(nn.Module):
 
     def forward(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.Tensor] = None, past_key_values: Optional[StaticCachePrealloc] = None,
-                cache_position: Optional[torch.Tensor] = None, logits_to_keep: int = 1
-                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                cache_position: Optional[torch.Tensor] = None, logits_to_keep: int = 1,
+                layer_hooks=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """layer_hooks = (before_mixer(i), after_mixer(i)) or None: called around the cache-touching part of
+        decoder layer i (used by dist.sequence_parallel_prefill to receive / forward that layer's state)."""
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         B, T, _ = inputs_embeds.shape
@@ -207,9 +217,13 @@ class InfiniteVLTextStack(nn.Module):
                 y = layer.input_layernorm(resid)
             else:
                 resid, y = layer.input_layernorm.add_and_norm(pend, resid)
+            if layer_hooks is not None:
+                layer_hooks[0](layer.self_attn.layer_idx)
             attn, _ = layer.self_attn(hidden_states=y, position_ids=position_ids, past_key_values=past_key_values,
                                       use_cache=past_key_values is not None, cache_position=cache_position,
                                       position_embeddings=position_embeddings)
+            if layer_hooks is not None:
+                layer_hooks[1](layer.self_attn.layer_idx)
             resid, y = layer.post_attention_layernorm.add_and_norm(attn, resid)
             pend = layer.mlp(y)
         if pend is None:

@@ -266,3 +266,105 @@ def test_gloo_world2_gather_and_max():
         assert p_.exitcode == 0
     for r, col, mx in res:
         assert col == [0.0, 1.0, 2.0, 3.0, 4.0] and mx == 2.0
+
+
+# ---- sequence-parallel prefill: schedule + per-layer state hand-off over gloo -------------------
+class _ToyLayerCache:
+    """A layer state with the cache contract dist.sequence_parallel_prefill relies on."""
+
+    def __init__(self, B, H):
+        self.state = torch.zeros(B, H, dtype=torch.float64)
+        self.ring = torch.zeros(B, 3, H, dtype=torch.float64)        # last 3 inputs (a sliding window)
+        self.seen = 0
+
+    def carried_tensors(self):
+        return [self.state, self.ring]
+
+    def import_carried(self, seen_tokens):
+        self.seen = int(seen_tokens)
+
+
+class _ToyCache:
+    def __init__(self, L, B, H):
+        self.layers = [_ToyLayerCache(B, H) for _ in range(L)]
+
+
+class _ToyStack:
+    """Token-recurrent toy layers whose output depends on ALL earlier tokens (decayed state) and on the last 3
+    inputs (window) and the absolute position: any lost / misordered / stale hand-off changes the result."""
+
+    def __init__(self, L):
+        self.decay = [0.5 + 0.1 * i for i in range(L)]
+
+    def __call__(self, inputs_embeds, position_ids, past_key_values, logits_to_keep=0, layer_hooks=None):
+        x = inputs_embeds.clone()
+        for i, a in enumerate(self.decay):
+            if layer_hooks is not None:
+                layer_hooks[0](i)
+            c = past_key_values.layers[i]
+            out = torch.empty_like(x)
+            for t in range(x.shape[1]):
+                c.state = a * c.state + x[:, t]
+                win = c.ring.sum(1)
+                out[:, t] = x[:, t] + c.state + 0.25 * win + 1e-3 * position_ids[0, :, t, None].double()
+                c.ring = torch.cat([c.ring[:, 1:], x[:, t:t + 1]], dim=1)
+            # the contract is in-place state: write back into the tensors carried_tensors() returned at creation
+            if layer_hooks is not None:
+                layer_hooks[1](i)
+            x = out
+        return x, None
+
+
+def _sp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from infinitevl_amd import dist as ivd
+    ivd.init_distributed("gloo")
+    B, H, L, total = 2, 5, 4, 150
+    torch.manual_seed(0)
+    xs = torch.randn(B, total, H, dtype=torch.float64)
+    first, last = ivd.segment_bounds(total, rank, world, multiple=64)          # 128 + 22
+    cache = _ToyCache(L, B, H)
+    h, _ = ivd.sequence_parallel_prefill(_ToyStack(L), xs[:, first:last], cache, first)
+    q.put((rank, first, last, h, [c.state.clone() for c in cache.layers], [c.seen for c in cache.layers]))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_sequence_parallel_prefill_matches_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    # single-process reference: the whole sequence through the same stack
+    B, H, L, total = 2, 5, 4, 150
+    torch.manual_seed(0)
+    xs = torch.randn(B, total, H, dtype=torch.float64)
+    cache = _ToyCache(L, B, H)
+    pos = torch.arange(total)[None, None].expand(3, B, total)
+    ref, _ = _ToyStack(L)(xs, pos, cache)
+    assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 128, 128, 150)
+    got = torch.cat([res[0][3], res[1][3]], dim=1)
+    assert torch.equal(got, ref)
+    for s_ref, s_got in zip([c.state for c in cache.layers], res[1][4]):       # last rank ends with the full state
+        assert torch.equal(s_ref, s_got)
+    assert res[1][5] == [128] * L and res[0][5] == [0] * L
+
+
+def test_segment_bounds_properties():
+    from infinitevl_amd.dist import segment_bounds
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 64, 65, 1000, 131072):
+            spans = [segment_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert all(a % 64 == 0 or a == total for a, _ in spans)           # boundaries are GDN chunk boundaries
+    with pytest.raises(ValueError):
+        segment_bounds(10, 2, 2)

@@ -8,6 +8,8 @@ Stated tolerances (SURVEY.md section 4 / fla:ops/utils/testing.py: RMS-relative 
     2e-3 only when the state itself is stored in bf16)
   * integers (window band, counters, ring placement) and M-RoPE: bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -791,3 +793,44 @@ def test_gdn_decode_step_equals_three_kernel_sequence(B, H, state_dtype):
         assert rms_rel(y_a.float().cpu(), y_b.float().cpu()) < 3e-3, step
         assert rms_rel(st_a.float().cpu(), st_b.float().cpu()) < (3e-3 if state_dtype == torch.bfloat16 else 1e-5), step
     assert torch.isfinite(y_b.float()).all()
+
+
+def test_carried_state_import_equals_continuing_on_the_same_cache():
+    """The hand-off contract of SURVEY.md 8f-4 inside one process: copy carried_tensors() of every layer into a fresh
+    cache + import_carried(), continue there; equals continuing on the original cache bit for bit."""
+    from infinitevl_amd.harness import InfiniteVLTextStack
+    hc, _ = parity.small_configs(window=96)
+    stack = InfiniteVLTextStack(hc).to(device=DEV, dtype=torch.bfloat16).eval()
+    stack.init_weights_(seed=7)
+    stack.fuse_()
+    torch.manual_seed(1)
+    xs = bf(torch.randn(1, 200, hc.hidden_size) * 0.5).to(DEV)
+    a, b = stack.allocate_inference_cache(1), stack.allocate_inference_cache(1)
+    with torch.no_grad():
+        stack(inputs_embeds=xs[:, :128], past_key_values=a, logits_to_keep=0)
+        for la, lb in zip(a.layers, b.layers):
+            for ta, tb in zip(la.carried_tensors(), lb.carried_tensors()):
+                tb.copy_(ta)
+            lb.import_carried(128)
+        pos = torch.arange(128, 200, device=DEV)[None, None].expand(3, 1, 72).contiguous()
+        h_b, _ = stack(inputs_embeds=xs[:, 128:], position_ids=pos, past_key_values=b, logits_to_keep=0)
+        h_a, _ = stack(inputs_embeds=xs[:, 128:], past_key_values=a, logits_to_keep=0)
+    assert torch.equal(h_a, h_b)
+    for la, lb in zip(a.layers, b.layers):
+        for ta, tb in zip(la.carried_tensors(), lb.carried_tensors()):
+            assert torch.equal(ta, tb)
+    assert a.get_seq_length() == b.get_seq_length() == 200
+
+
+def test_sequence_parallel_prefill_two_ranks_bit_exact():
+    """SURVEY.md 8f-4: one sequence cut in two segments, two processes, per-layer state hand-off (tools/sp_check.py);
+    the result equals the single-process two-call sequence bit for bit (hidden, cache, following decode steps)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() % 200)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "sp_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SP_CHECK PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
