@@ -26,7 +26,8 @@ constexpr int SWA_KSTRIDE = 272;     // bytes per K row in LDS (padded: linear a
 constexpr int SWA_VSTRIDE = 288;     // bytes per V row in LDS (padded)
 constexpr int SWA_LDS_K = SWA_KT * SWA_KSTRIDE;
 constexpr int SWA_LDS_BYTES = SWA_LDS_K + SWA_KT * SWA_VSTRIDE;
-constexpr int SWA_MAX_SPLIT = 16;
+constexpr int SWA_MAX_SPLIT = 16;        // prefill / split-KV with register-resident combine
+constexpr int SWA_MAX_SPLIT_PACK = 64;   // packed decode rows: one 64-key tile per workgroup
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct SwaParams {
@@ -436,6 +437,44 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
   }
 }
 
+// merge up to 64 split-KV partials (packed decode): one wavefront per (b, t, head) row.  Lane s first owns split s
+// (its running max / sum -> weight 2^(m_s - m)), then the wave walks the splits with the weights broadcast by
+// v_readlane while every lane accumulates its 2 d-values; loads are issued 8 splits at a time.
+__global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                              bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit) {
+  const int lane = threadIdx.x & 63;
+  const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
+    const long long b = r / rows_per_b, rr = r % rows_per_b;
+    const bool on = lane < nsplit;
+    const float2 ml = *(const float2*)(part_ml + ((b * nsplit + (on ? lane : 0)) * rows_per_b + rr) * 2);
+    const float ms = on ? ml.x : -INFINITY;
+    float m = ms;
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) m = fmaxf(m, __shfl_xor(m, ofs, 64));
+    const float w = ms == -INFINITY ? 0.f : exp2f(ms - m);
+    const float l = wave_sum(w * (on ? ml.y : 0.f));
+    float a0 = 0.f, a1 = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+      float2 ov[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s2 = min(s0 + j, nsplit - 1);
+        ov[j] = *(const float2*)(part_o + ((b * nsplit + s2) * rows_per_b + rr) * SWA_D + 2 * lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ws = s0 + j < nsplit ? __shfl(w, s0 + j, 64) : 0.f;
+        a0 = fmaf(ws, ov[j].x, a0);
+        a1 = fmaf(ws, ov[j].y, a1);
+      }
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    *(unsigned int*)(o + r * SWA_D + 2 * lane) = pack2bf(a0 * inv, a1 * inv);
+  }
+}
+
 // ring append: token t of the call -> slot (pos + t) % C ; only the last min(T, C) tokens are written
 __global__ __launch_bounds__(256) void swa_cache_append_kernel(
     const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, long long kn_sb, long long kn_st, long long kn_sh,
@@ -497,7 +536,7 @@ using namespace ivl;
 extern "C" size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d) {
   if (B <= 0 || T <= 0 || Hq <= 0 || d != SWA_D) return 0;
   int ns = swa_base_nsplit(B, T, Hq);
-  if (T <= SWA_QT) ns = SWA_MAX_SPLIT;      // packed decode rows may use the maximum split
+  if (T <= SWA_QT) ns = SWA_MAX_SPLIT_PACK;      // packed decode rows may use the maximum split
   if (ns == 1) return 256;
   return (size_t)B * ns * T * Hq * (SWA_D + 2) * sizeof(float) + 256;
 }
@@ -521,12 +560,13 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   const int max_tiles = (int)(span / SWA_KT) + 2;
   int nsplit = 1;
   if (pack) {
-    nsplit = max_tiles / 2;
+    nsplit = max_tiles;                    // decode: one key tile per workgroup (the K/V read is the whole cost)
+    if (nsplit > SWA_MAX_SPLIT_PACK) nsplit = SWA_MAX_SPLIT_PACK;
   } else {
     nsplit = swa_base_nsplit(a->B, a->T, a->Hq);
     if (nsplit > max_tiles / 4) nsplit = max_tiles / 4;
+    if (nsplit > SWA_MAX_SPLIT) nsplit = SWA_MAX_SPLIT;
   }
-  if (nsplit > SWA_MAX_SPLIT) nsplit = SWA_MAX_SPLIT;
   if (nsplit < 1) nsplit = 1;
 
   SwaParams p;
@@ -567,7 +607,8 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     const long long nrows = (long long)a->B * a->T * a->Hq;
     long long gb = (nrows * 64 + 255) / 256;
     if (gb > 4096) gb = 4096;
-    if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    if (nsplit > 16) hipLaunchKernelGGL(swa_combine_wide_kernel, dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    else if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
     else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
     else hipLaunchKernelGGL((swa_combine_kernel<16>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
     rc = check_launch("ivl_swa_fwd(combine)");
