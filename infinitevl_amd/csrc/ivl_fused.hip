@@ -13,8 +13,9 @@
 namespace ivl {
 
 constexpr int FC_W = 4;       // conv taps
-// tokens per conv thread: 8 for long calls (3 halo rows re-read per 8 tokens); 2 for the 256-token step, where 8
-// would leave half the chip idle (128 workgroups; 7.8 -> 5.3 us)
+// tokens per conv thread: 8 for long calls (3 halo rows re-read per 8 tokens); 4 for the 256-token step, where 8
+// would leave half the chip idle (128 workgroups; 7.8 -> 6.0 us).  Not below 4: only the thread of chunk 0 may touch
+// the carried state (it is updated in place), so chunk 1 must start at a token >= 3.
 
 struct ConvSeg {
   const bf16_t* w;            // [D,4]
@@ -43,7 +44,7 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
 }
 
-template <int FC_TCH>
+template <int FC_TCH>      // >= 3 (see above)
 __global__ __launch_bounds__(256) void gdn_prologue_kernel(ProParams p) {
   if ((int)blockIdx.x >= p.conv_blocks) {
     // ---- gate math: beta = sigmoid(b) ; g = -exp(A_log) softplus(a + dt_bias) (std:1293-1294) ---------
@@ -318,11 +319,11 @@ extern "C" int ivl_gdn_prologue_fwd(const void* proj, int64_t ld, int col_q, int
   p.seg[2] = ConvSeg{(const bf16_t*)w_v, (const bf16_t*)sv_in, (bf16_t*)sv_out, (bf16_t*)v, col_v, Dv};
   p.col_a = col_a; p.col_b = col_b; p.A_log = A_log; p.dt_bias = dt_bias; p.g = g; p.beta = (bf16_t*)beta;
   p.B = B; p.T = T; p.H = H; p.apply_silu = apply_silu;
-  const int tch = T <= 1024 ? 2 : 8;
+  const int tch = T <= 1024 ? 4 : 8;
   const long long conv_items = (long long)B * ((T + tch - 1) / tch) * ((Dq + Dk + Dv) / 8);
   p.conv_blocks = grid_cap(conv_items);
   const int gate_blocks = grid_cap((long long)B * T * H, 256, 64);
-  if (tch == 2) hipLaunchKernelGGL(gdn_prologue_kernel<2>, dim3(p.conv_blocks + gate_blocks), dim3(256), 0, (hipStream_t)stream, p);
+  if (tch == 4) hipLaunchKernelGGL(gdn_prologue_kernel<4>, dim3(p.conv_blocks + gate_blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gdn_prologue_kernel<8>, dim3(p.conv_blocks + gate_blocks), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("ivl_gdn_prologue_fwd");
 }
