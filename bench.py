@@ -223,7 +223,7 @@ def pmc_traffic(kernel_name, chunk, window):
     k = json.load(open(files[-1]))["kernels"]
     want = {
         "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel", 16384), ("ivl::gdn_chunk_scan_kernel", 32768)],
-        "swa_prefill": [("ivl::swa_fwd_kernel<false, true", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
+        "swa_prefill": [("ivl::swa_fwd_kernel<false,", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
         "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 36864)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
         "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],

@@ -106,7 +106,7 @@ __device__ __forceinline__ void store16_f32(float* Cm, int ldc, int r0, int c0, 
 __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const float* __restrict__ g, const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws,
-    int T, int H, int t_seg0, int nt_seg, int l2norm, int dbg_stop, long long* trace) {
+    int T, int H, int t_seg0, int nt_seg, int l2norm, long long* trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
@@ -211,7 +211,6 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();
 
   trace_stamp(trace, 1);
-  if (dbg_stop == 1) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S1b: bf16(beta k_hat) row-major to LDS (beta v follows once k_hat/q_hat are dead) -------------
   {
 #pragma unroll
@@ -226,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();
 
   trace_stamp(trace, 2);
-  if (dbg_stop == 2) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S2: L = tril(kb kh^T, -1) -> s_L (fp32);  Aqk = tril((qh kh^T) * Gamma) -> global bf16 ------
   //          wave w -> 32x32 tile (mi = w>>1, ni = w&1); tile (0,1) lies above the diagonal.
   {
@@ -269,7 +267,6 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();
 
   trace_stamp(trace, 3);
-  if (dbg_stop == 3) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- Qh and KdT leave now (their stores overlap the solve); afterwards k_hat/q_hat are dead -----------
   for (int idx = tid; idx < GC * (GK / 8); idx += 256) {
     const int row = idx >> 4, ch = idx & 15;
@@ -350,9 +347,7 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();
 
   trace_stamp(trace, 4);
-  if (dbg_stop == 4) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   trace_stamp(trace, 5);
-  if (dbg_stop == 5) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S5: w = bf16(Tw) kb  (64x64 . 64x128): wave w -> columns 32w..32w+31, both row tiles.
   //          A fragments are built straight from the fp32 T in LDS (rounded to bf16 in registers:
   //          the reference stores Aw/Au in bf16, wy_fast.py:341-343). ------------------------------
@@ -412,7 +407,6 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
   }
 
   trace_stamp(trace, 6);
-  if (dbg_stop == 6) return;   // timing ladder (IVL_DEBUG_PREP_STOP)
   // ---- S6: u = Tu vb  (64x64 . 64x256): wave w -> columns 64w..64w+63 ; UT[col][time] to global --
   {
 #pragma unroll
@@ -741,16 +735,6 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SC_BYTES);
     attr_set = true;
   }
-  static int dbg_stop = -1;
-  if (dbg_stop < 0) {
-    const char* e = getenv("IVL_DEBUG_PREP_STOP");
-    dbg_stop = e ? atoi(e) : 0;
-  }
-  static int dbg_skip_scan = -1;
-  if (dbg_skip_scan < 0) {
-    const char* e = getenv("IVL_DEBUG_SKIP_SCAN");
-    dbg_skip_scan = e ? atoi(e) : 0;
-  }
   hipStream_t st = (hipStream_t)stream;
   const int NT = (T + GC - 1) / GC;
   const int segc = seg_chunks(NT);
@@ -761,14 +745,13 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     const bool first = c0 == 0, last = c0 + nseg >= NT;
     hipLaunchKernelGGL(gdn_chunk_prepare_kernel, dim3(nseg, B * H), dim3(256), P_BYTES, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb,
-                       T, H, c0 * GC, nseg, use_qk_l2norm, dbg_stop, debug_trace_buffer());
+                       T, H, c0 * GC, nseg, use_qk_l2norm, debug_trace_buffer());
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
     if (rc != IVL_OK) return rc;
     const void* hin = first ? h0 : (const void*)carry;
     const int hin_dt = first ? h0_dtype : IVL_F32;
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
-    if (dbg_skip_scan) continue;
     hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(B * H, GV / G_BV), dim3(256), SC_BYTES, st,
                        (const unsigned char*)wsb, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale, debug_trace_buffer());
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");

@@ -77,7 +77,7 @@ __device__ __forceinline__ float group_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <bool PACK, bool TR, int QG>
+template <bool PACK, int QG>
 __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SWA_LDS_BYTES];
   constexpr int QT = SWA_QT * QG;      // query rows per workgroup
@@ -340,31 +340,17 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     for (int mt2 = 0; mt2 < 8; ++mt2) {
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
-        u32x4 vf;
-        if (TR) {
-          // 16-lane group g reads the 4x16 block rows (32ks2 [+16] + 4g .. +3), cols 16mt2..+15;
-          // lane i supplies the address of row (i>>2), cols 4(i&3)..+3 and receives column i.
-          const int r0 = 32 * ks2 + 4 * g + (l15 >> 2);
-          const int cb = (16 * mt2 + 4 * (l15 & 3)) * 2;
-          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + r0 * SWA_VSTRIDE + cb));
-          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + (r0 + 16) * SWA_VSTRIDE + cb));
-          u32x2 w0, w1;
-          __builtin_memcpy(&w0, &a0, 8);
-          __builtin_memcpy(&w1, &a1, 8);
-          vf = u32x4{w0.x, w0.y, w1.x, w1.y};
-        } else {
-          const int col = (16 * mt2 + l15) * 2;
-          const int r0 = 32 * ks2 + 4 * g;
-          unsigned short e[8];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            e[i] = *(const unsigned short*)(vbase + (r0 + i) * SWA_VSTRIDE + col);
-            e[4 + i] = *(const unsigned short*)(vbase + (r0 + 16 + i) * SWA_VSTRIDE + col);
-          }
-          vf = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                     (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-        }
+        // 16-lane group g reads the 4x16 block rows (32ks2 [+16] + 4g .. +3), cols 16mt2..+15;
+        // lane i supplies the address of row (i>>2), cols 4(i&3)..+3 and receives column i.
+        const int r0 = 32 * ks2 + 4 * g + (l15 >> 2);
+        const int cb = (16 * mt2 + 4 * (l15 & 3)) * 2;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + r0 * SWA_VSTRIDE + cb));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + (r0 + 16) * SWA_VSTRIDE + cb));
+        u32x2 w0, w1;
+        __builtin_memcpy(&w0, &a0, 8);
+        __builtin_memcpy(&w1, &a1, 8);
+        const u32x4 vf = u32x4{w0.x, w0.y, w1.x, w1.y};
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg)
           oacc[qg][mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_mfma(vf), as_mfma(pf[qg][ks2]), oacc[qg][mt2], 0, 0, 0);
@@ -520,15 +506,6 @@ static int swa_base_nsplit(int B, int T, int Hq) {
   return (int)ns;
 }
 
-static bool swa_use_tr() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("IVL_SWA_NO_TR");
-    v = (e && e[0] == '1') ? 0 : 1;
-  }
-  return v == 1;
-}
-
 }  // namespace ivl
 
 using namespace ivl;
@@ -590,17 +567,9 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.n_qtiles = (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
   hipStream_t st = (hipStream_t)stream;
-  const bool tr = swa_use_tr();
-  if (pack) {
-    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<true, true, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((swa_fwd_kernel<true, false, 1>), grid, dim3(256), 0, st, p);
-  } else if (qg == 2) {
-    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((swa_fwd_kernel<false, false, 2>), grid, dim3(256), 0, st, p);
-  } else {
-    if (tr) hipLaunchKernelGGL((swa_fwd_kernel<false, true, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((swa_fwd_kernel<false, false, 1>), grid, dim3(256), 0, st, p);
-  }
+  if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);
+  else if (qg == 2) hipLaunchKernelGGL((swa_fwd_kernel<false, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p);
   int rc = check_launch("ivl_swa_fwd");
   if (rc != IVL_OK) return rc;
   if (nsplit > 1) {

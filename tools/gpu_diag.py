@@ -225,7 +225,7 @@ def main():
     args = ap.parse_args()
     import infinitevl_amd
     infinitevl_amd.load_library()
-    print("device:", torch.cuda.get_device_name(0), "| IVL_SWA_NO_TR =", os.environ.get("IVL_SWA_NO_TR", ""))
+    print("device:", torch.cuda.get_device_name(0))
     for fn in CHECKS:
         name = fn._check_name
         if args.only and args.only not in name:
