@@ -6,13 +6,15 @@
 // rounding points (conv output, l2norm output, beta, o are rounded to bf16 where those kernels store bf16).
 // A decode step is launch-bound (~430 launches per token in the 36-layer stack): this removes two per GDN layer.
 //
-// One workgroup per (batch, head), 4 waves.  State S[128][256] lives in registers: wave w owns rows 32w..32w+31,
+// One workgroup per (batch, head), 8 waves.  State S[128][256] lives in registers: wave w owns rows 16w..16w+15,
 // lane l owns columns 4l..4l+3 (a wave reads/writes one whole 512-byte state row per instruction).
 #include "ivl_common.h"
 
 namespace ivl {
 
 constexpr int DK = 128, DV = 256;
+constexpr int DNW = 8;                 // waves per workgroup
+constexpr int DRW = DK / DNW;          // state rows per wave
 
 struct DecParams {
   const bf16_t* proj; long long ld;
@@ -40,9 +42,9 @@ __device__ __forceinline__ float conv1(const bf16_t* xrow, int col, const bf16_t
   return bf_round(a * sigmoidf_(a));
 }
 
-__global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
+__global__ __launch_bounds__(64 * DNW) void gdn_decode_step_kernel(DecParams p) {
   __shared__ __attribute__((aligned(16))) float s_k[DK], s_q[DK], s_v[DV];
-  __shared__ __attribute__((aligned(16))) float s_red[4][2][DV];
+  __shared__ __attribute__((aligned(16))) float s_red[DNW][2][DV];
   __shared__ float s_part[4][2];
   __shared__ float s_sc[4];          // decay, beta, k.q
 
@@ -51,35 +53,36 @@ __global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
   const bf16_t* xrow = p.proj + (long long)b * p.ld;
 
   // ---- state rows of this wave: issue every load up front --------------------------------------------
-  float S[32][4];
-  const size_t sbase = ((size_t)bh * DK + 32 * wave) * DV + 4 * lane;
+  float S[DRW][4];
+  const size_t sbase = ((size_t)bh * DK + DRW * wave) * DV + 4 * lane;
   if (p.state_dtype == IVL_F32) {
     const float* sp = (const float*)p.state + sbase;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < DRW; ++r) {
       const f32x4 v4 = *(const f32x4*)(sp + (size_t)r * DV);
       S[r][0] = v4[0]; S[r][1] = v4[1]; S[r][2] = v4[2]; S[r][3] = v4[3];
     }
   } else {
     const bf16_t* sp = (const bf16_t*)p.state + sbase;
-    u32x2 raw[32];
+    u32x2 raw[DRW];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) raw[r] = *(const u32x2*)(sp + (size_t)r * DV);
+    for (int r = 0; r < DRW; ++r) raw[r] = *(const u32x2*)(sp + (size_t)r * DV);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < DRW; ++r) {
       S[r][0] = bflo(raw[r].x); S[r][1] = bfhi(raw[r].x); S[r][2] = bflo(raw[r].y); S[r][3] = bfhi(raw[r].y);
     }
   }
 
   // ---- convs: thread t -> q channel t (t < 128) or k channel t-128, and v channel t -------------------
   const int Dq = p.H * DK, Dv = p.H * DV;
-  float qk;
-  if (tid < DK) qk = conv1(xrow, p.col_q + h * DK + tid, p.wq, h * DK + tid, p.cq, (size_t)b * Dq + h * DK + tid);
+  float qk = 0.f;
+  if (tid >= 2 * DK) {
+    // waves 4..7 only hold state rows; the 256 conv / l2norm lanes are waves 0..3
+  } else if (tid < DK) qk = conv1(xrow, p.col_q + h * DK + tid, p.wq, h * DK + tid, p.cq, (size_t)b * Dq + h * DK + tid);
   else qk = conv1(xrow, p.col_k + h * DK + (tid - DK), p.wk, h * DK + tid - DK, p.ck, (size_t)b * Dq + h * DK + (tid - DK));
-  const float vv = conv1(xrow, p.col_v + h * DV + tid, p.wv, h * DV + tid, p.cv, (size_t)b * Dv + h * DV + tid);
-  s_v[tid] = vv;
+  if (tid < DV) s_v[tid] = conv1(xrow, p.col_v + h * DV + tid, p.wv, h * DV + tid, p.cv, (size_t)b * Dv + h * DV + tid);
   // l2norm: q in waves 0,1 ; k in waves 2,3
-  {
+  if (wave < 4) {
     const float ss = wave_sum(qk * qk);
     if (lane == 0) s_part[wave][0] = ss;
   }
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
     s_sc[1] = bf_round(1.0f / (1.0f + expf(-bv)));
   }
   __syncthreads();
-  {
+  if (tid < 2 * DK) {
     const float tot = tid < DK ? s_part[0][0] + s_part[1][0] : s_part[2][0] + s_part[3][0];
     const float nrm = bf_round(qk * (1.0f / sqrtf(tot + 1e-6f)));       // fla l2norm_fwd writes bf16
     if (tid < DK) s_q[tid] = nrm * p.scale;
@@ -103,14 +106,14 @@ __global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
   // k . (q*scale): every wave computes it redundantly (2 elements per lane)
   const float kq = wave_sum(s_k[2 * lane] * s_q[2 * lane] + s_k[2 * lane + 1] * s_q[2 * lane + 1]);
 
-  // ---- decay + the two column reductions over this wave's 32 rows --------------------------------------
+  // ---- decay + the two column reductions over the rows of this wave --------------------------------------
   const float decay = s_sc[0], beta = s_sc[1];
   float pk[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
-  float kk[32];
+  float kk[DRW];
 #pragma unroll
-  for (int r4 = 0; r4 < 8; ++r4) {
-    const f32x4 k4 = *(const f32x4*)&s_k[32 * wave + 4 * r4];
-    const f32x4 q4 = *(const f32x4*)&s_q[32 * wave + 4 * r4];
+  for (int r4 = 0; r4 < DRW / 4; ++r4) {
+    const f32x4 k4 = *(const f32x4*)&s_k[DRW * wave + 4 * r4];
+    const f32x4 q4 = *(const f32x4*)&s_q[DRW * wave + 4 * r4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * r4 + i;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
   {
     f32x4 kv = *(const f32x4*)&s_red[0][0][4 * lane], oq = *(const f32x4*)&s_red[0][1][4 * lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < DNW; ++w) {
       kv += *(const f32x4*)&s_red[w][0][4 * lane];
       oq += *(const f32x4*)&s_red[w][1][4 * lane];
     }
@@ -143,17 +146,17 @@ __global__ __launch_bounds__(256) void gdn_decode_step_kernel(DecParams p) {
   }
   // ---- state update + write-back -------------------------------------------------------------------
 #pragma unroll
-  for (int r = 0; r < 32; ++r)
+  for (int r = 0; r < DRW; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) S[r][c] = fmaf(kk[r], delta[c], S[r][c]);
   if (p.state_dtype == IVL_F32) {
     float* sp = (float*)p.state + sbase;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) *(f32x4*)(sp + (size_t)r * DV) = f32x4{S[r][0], S[r][1], S[r][2], S[r][3]};
+    for (int r = 0; r < DRW; ++r) *(f32x4*)(sp + (size_t)r * DV) = f32x4{S[r][0], S[r][1], S[r][2], S[r][3]};
   } else {
     bf16_t* sp = (bf16_t*)p.state + sbase;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) *(u32x2*)(sp + (size_t)r * DV) = u32x2{pack2bf(S[r][0], S[r][1]), pack2bf(S[r][2], S[r][3])};
+    for (int r = 0; r < DRW; ++r) *(u32x2*)(sp + (size_t)r * DV) = u32x2{pack2bf(S[r][0], S[r][1]), pack2bf(S[r][2], S[r][3])};
   }
   // ---- gated RMSNorm over the head's 256 outputs (every wave holds all of them, 4 per lane) -----------
   if (wave == 0) {
@@ -194,6 +197,6 @@ extern "C" int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, 
   p.cq = (bf16_t*)conv_state_q; p.ck = (bf16_t*)conv_state_k; p.cv = (bf16_t*)conv_state_v;
   p.A_log = A_log; p.dt_bias = dt_bias; p.norm_w = (const bf16_t*)norm_weight; p.eps = eps;
   p.state = state; p.state_dtype = state_dtype; p.y = (bf16_t*)y; p.H = H; p.scale = scale;
-  hipLaunchKernelGGL(gdn_decode_step_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gdn_decode_step_kernel, dim3(B * H), dim3(64 * DNW), 0, (hipStream_t)stream, p);
   return check_launch("ivl_gdn_decode_step_fwd");
 }
