@@ -282,7 +282,10 @@ def cpu_baseline(chunk, window):
 def main():
     args = parse()
     from infinitevl_amd import dist as ivd
-    rank, world, local_rank = ivd.init_distributed("nccl")
+    # IVL_DIST_BACKEND=gloo lets the N > 1 control flow be exercised with several ranks on ONE GPU (RCCL refuses two
+    # ranks per device); production is always "nccl" (= RCCL over xGMI)
+    rank, world, local_rank = ivd.init_distributed(os.environ.get("IVL_DIST_BACKEND", "nccl"))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
