@@ -19,7 +19,7 @@ import torch  # noqa: E402
 
 from oracle import gdn as ogdn  # noqa: E402
 from oracle import swa as oswa  # noqa: E402
-from tools import parity  # noqa: E402
+import parity  # noqa: E402  (tests/ is this script's directory)
 
 RESULTS = {}
 

@@ -1,7 +1,7 @@
 """Parity helpers: run the HIP path (through the C ABI) and the CPU oracle on the same seeded
-inputs and return error metrics.  Used by tests/ (-m gpu), __graft_entry__.smoke() and
-tools/gpu_diag.py.  TEST INFRASTRUCTURE: this is the only place (besides tests/ and bench.py's
-cpu_baseline leg) that imports `oracle`."""
+inputs and return error metrics.  Used by the -m gpu tests, __graft_entry__.smoke() and tests/gpu_diag.py.
+TEST INFRASTRUCTURE: lives under tests/ because it imports `oracle` (only tests/, smoke() and bench.py's cpu_baseline
+leg may)."""
 from __future__ import annotations
 
 from typing import Dict, Optional

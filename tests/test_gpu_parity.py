@@ -17,7 +17,7 @@ import torch
 from conftest import load_golden, rms_rel
 from oracle import gdn as ogdn
 from oracle import swa as oswa
-from tools import parity
+import parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
