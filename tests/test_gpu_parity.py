@@ -222,6 +222,8 @@ SWA_CASES = [
     (1, 70, 2, 1, 96, 250, "ring"), (1, 256, 16, 2, 4096, 4500, "ring"), (1, 256, 16, 2, 4096, 1000, "ring"),
     (1, 1, 16, 2, 4096, 5000, "ring"), (2, 1, 16, 2, 96, 40, "ring"), (1, 3, 16, 2, 96, 500, "ring"),
     (1, 300, 2, 1, 96, 77, "ring"), (1, 64, 16, 2, 8192, 8191, "ring"), (1, 1, 16, 2, 2, 5, "ring"),
+    # packed multi-token decode rows over a full window: 64-way split + wide combine
+    (1, 4, 16, 2, 4096, 6000, "ring"), (2, 2, 16, 2, 4096, 4500, "ring"), (1, 8, 16, 2, 2048, 1500, "ring"),
 ]
 
 
