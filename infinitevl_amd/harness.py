@@ -10,7 +10,7 @@ stock PyTorch-ROCm (rocBLAS/hipBLASLt GEMMs): callers of the path, kept as-is.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, fields
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -62,6 +62,19 @@ class InfiniteVLTextConfig:
         if self.layer_types is None:            # configuration_infinitevl.py:278-284: every 4th layer is SWA
             self.layer_types = ["sliding_attention" if i % 4 == 0 else "linear_attention"
                                 for i in range(self.num_hidden_layers)]
+
+    @classmethod
+    def from_hf_config(cls, cfg) -> "InfiniteVLTextConfig":
+        """From the reference's config.json (path or dict): text fields live at the top level or under `text_config`
+        (configuration_infinitevl.py:287-330); unknown keys (vision_config, token ids, ...) are ignored."""
+        if isinstance(cfg, (str, bytes, _os.PathLike)):
+            import json
+            with open(cfg) as f:
+                cfg = json.load(f)
+        src = dict(cfg)
+        src.update(cfg.get("text_config") or {})
+        names = {f_.name for f_ in fields(cls)}
+        return cls(**{k: v for k, v in src.items() if k in names and v is not None})
 
 
 class InfiniteVLRMSNorm(nn.Module):
@@ -234,6 +247,56 @@ class InfiniteVLTextStack(nn.Module):
         if logits_to_keep:
             logits = ops.linear(h[:, -logits_to_keep:, :], self.embed_tokens.weight)  # tied lm_head (std:2091-2092)
         return h, logits
+
+
+_TEXT_PREFIXES = ("model.language_model.", "language_model.model.", "language_model.", "model.")
+
+
+def text_state_dict_from_reference(tensors) -> Tuple[Dict[str, torch.Tensor], List[str]]:
+    """Map the reference checkpoint's tensor names onto InfiniteVLTextStack's (std:1595-1618, 1975-1987): the text
+    decoder lives under `model.language_model.` (current layout) or `model.` (Qwen2.5-VL legacy layout, remapped by
+    `_checkpoint_conversion_mapping`); the vision tower (`visual.` / `model.visual.`) and the tied `lm_head.weight`
+    are not part of the path.  Returns (state_dict for the stack, skipped names)."""
+    out, skipped = {}, []
+    for name, t in tensors.items():
+        if name.startswith(("visual.", "model.visual.")) or name == "lm_head.weight":
+            skipped.append(name)
+            continue
+        for pre in _TEXT_PREFIXES:
+            if name.startswith(pre):
+                out[name[len(pre):]] = t
+                break
+        else:
+            skipped.append(name)
+    return out, skipped
+
+
+@torch.no_grad()
+def load_reference_checkpoint(stack: "InfiniteVLTextStack", path: str) -> List[str]:
+    """Load the text decoder of a reference checkpoint directory (`*.safetensors`, sharded or not) or file into
+    `stack` (call BEFORE fuse_()).  Every text parameter must be present with the right shape; returns the names
+    that were skipped (vision tower, tied lm_head)."""
+    import glob
+    from safetensors import safe_open
+    files = sorted(glob.glob(_os.path.join(path, "*.safetensors"))) if _os.path.isdir(path) else [path]
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    tensors = {}
+    for fpath in files:
+        with safe_open(fpath, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+    sd, skipped = text_state_dict_from_reference(tensors)
+    own = stack.state_dict()
+    missing = [k for k in own if k not in sd and "inv_freq" not in k]
+    unexpected = [k for k in sd if k not in own]
+    if missing or unexpected:
+        raise KeyError(f"checkpoint does not match the text stack: missing {missing[:5]} unexpected {unexpected[:5]}")
+    for k, v in sd.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != {tuple(own[k].shape)}")
+        own[k].copy_(v.to(own[k].dtype))
+    return skipped
 
 
 def clone_inference_cache(cache: StaticCachePrealloc) -> StaticCachePrealloc:

@@ -221,6 +221,66 @@ def test_module_parameter_names_match_reference_checkpoint_layout():
         assert ours == ref, (i, set(ours) ^ set(ref))
 
 
+def _tiny_cfg(z):
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    lt = [str(x) for x in z["layer_types"]]
+    return InfiniteVLTextConfig(vocab_size=97, hidden_size=64, intermediate_size=96, num_hidden_layers=4,
+                                num_attention_heads=4, num_key_value_heads=2, head_dim=16, sliding_window=8,
+                                layer_types=lt, num_linear_heads=4, num_linear_key_value_heads=4, linear_head_dim=16,
+                                rope_scaling={"mrope_section": [2, 3, 3]})
+
+
+@pytest.mark.parametrize("prefix", ["model.language_model.", "model."])
+def test_load_reference_checkpoint_layouts(tmp_path, prefix):
+    """The reference checkpoint's tensor names (current `model.language_model.*` and legacy `model.*` layouts, vision
+    tower and tied lm_head alongside) load into the drop-in text stack; values = the reference state_dict fixture."""
+    from safetensors.torch import save_file
+    from infinitevl_amd.harness import InfiniteVLTextStack, load_reference_checkpoint
+    z = load_golden("tiny_stack")
+    ref = {k[2:]: v.clone() for k, v in z.items() if k.startswith("w.")}
+    ckpt = {prefix + k: v.contiguous() for k, v in ref.items()}
+    vis = ("model.visual." if prefix != "model." else "visual.") + "blocks.0.attn.qkv.weight"
+    ckpt[vis] = torch.zeros(3, 3)
+    ckpt["lm_head.weight"] = ref["embed_tokens.weight"].clone()
+    half = len(ckpt) // 2
+    names = sorted(ckpt)
+    save_file({k: ckpt[k] for k in names[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: ckpt[k] for k in names[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    stack = InfiniteVLTextStack(_tiny_cfg(z))
+    skipped = load_reference_checkpoint(stack, str(tmp_path))
+    assert sorted(skipped) == sorted([vis, "lm_head.weight"])
+    sd = stack.state_dict()
+    for k, v in ref.items():
+        assert torch.equal(sd[k].float(), v.float()), k
+    # a checkpoint that lacks a text tensor, or carries a wrong shape, is refused
+    bad = dict(ckpt)
+    del bad[prefix + "norm.weight"]
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(KeyError):
+        load_reference_checkpoint(InfiniteVLTextStack(_tiny_cfg(z)), str(tmp_path / "bad.safetensors"))
+    bad = dict(ckpt)
+    bad[prefix + "norm.weight"] = torch.zeros(3)
+    save_file(bad, str(tmp_path / "bad2.safetensors"))
+    with pytest.raises(ValueError):
+        load_reference_checkpoint(InfiniteVLTextStack(_tiny_cfg(z)), str(tmp_path / "bad2.safetensors"))
+
+
+def test_text_config_from_reference_config_json():
+    """The shipped InfiniteVL-3B config.json values (top-level text fields + ignored vision / token-id keys)."""
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    cfg = {"architectures": ["InfiniteVLQwen2_5_VLForConditionalGeneration"], "hidden_size": 2048, "intermediate_size": 11008,
+           "num_hidden_layers": 36, "num_attention_heads": 16, "num_key_value_heads": 2, "rms_norm_eps": 1e-06,
+           "rope_theta": 1000000.0, "sliding_window": 8192, "tie_word_embeddings": True, "vocab_size": 151936,
+           "rope_scaling": {"mrope_section": [16, 24, 24], "rope_type": "default", "type": "default"},
+           "vision_config": {"hidden_size": 1280}, "image_token_id": 151655, "text_config": {"sliding_window": 4096}}
+    c = InfiniteVLTextConfig.from_hf_config(cfg)
+    assert (c.hidden_size, c.num_hidden_layers, c.num_key_value_heads, c.vocab_size) == (2048, 36, 2, 151936)
+    assert c.sliding_window == 4096                      # text_config overrides the top level
+    assert c.layer_types[:5] == ["sliding_attention", "linear_attention", "linear_attention", "linear_attention",
+                                 "sliding_attention"] and len(c.layer_types) == 36
+    assert c == InfiniteVLTextConfig(sliding_window=4096, rope_scaling=cfg["rope_scaling"])
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-GPU host logic on CPU: gloo, world_size 2
 # ---------------------------------------------------------------------------------------------
