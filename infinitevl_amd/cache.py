@@ -357,6 +357,101 @@ class StaticLinearLayerPrealloc(_HFLayer):
         self.seq_len, self.start = other.seq_len, other.start
 
 
+class DynamicLayer(_HFLayer):
+    """Growing K/V cache for a full-attention layer (strm:67-157): the fallback the aggregate cache uses for layer
+    types that are neither sliding nor linear.  InfiniteVL's shipped config has none; kept so that the dispatch by
+    `layer_types` is total.  Pure tensor bookkeeping (torch.cat), the attention itself runs through
+    `swa_attention_interface` with window=None (plain causal)."""
+    is_sliding = False
+
+    def __init__(self):
+        if _HFLayer is not object:
+            super().__init__()
+        self._k: Optional[torch.Tensor] = None
+        self._v: Optional[torch.Tensor] = None
+        self.is_initialized = False
+
+    @property
+    def keys(self):
+        return self._k
+
+    @keys.setter
+    def keys(self, value):            # HF's CacheLayerMixin.__init__ assigns None
+        self._k = value
+
+    @property
+    def values(self):
+        return self._v
+
+    @values.setter
+    def values(self, value):
+        self._v = value
+
+    def lazy_initialization(self, key_states: torch.Tensor, *a, **k):
+        self.dtype, self.device = key_states.dtype, key_states.device
+        self._k = key_states.new_empty(0)
+        self._v = key_states.new_empty(0)
+        self.is_initialized = True
+
+    def update(self, key_states, value_states, conv_state=None, recurrent_state=None, cache_kwargs=None):
+        if not self.is_initialized:
+            self.lazy_initialization(key_states)
+        self._k = key_states if self._k.numel() == 0 else torch.cat([self._k, key_states], dim=-2)
+        self._v = value_states if self._v.numel() == 0 else torch.cat([self._v, value_states], dim=-2)
+        return self._k, self._v
+
+    def get_mask_sizes(self, cache_position: torch.Tensor) -> Tuple[int, int]:
+        return self.get_seq_length(), 0
+
+    def get_seq_length(self, *a, **k) -> int:
+        return 0 if (not self.is_initialized or self._k.numel() == 0) else int(self._k.shape[-2])
+
+    def get_max_cache_shape(self) -> int:
+        return -1
+
+    def get_max_length(self) -> int:
+        return -1
+
+    def crop(self, max_length: int) -> None:
+        if max_length < 0:
+            max_length = self.get_seq_length() - abs(max_length)
+        if self.get_seq_length() <= max_length:
+            return
+        self._k, self._v = self._k[..., :max_length, :], self._v[..., :max_length, :]
+
+    def batch_repeat_interleave(self, repeats: int) -> None:
+        if self.get_seq_length() > 0:
+            self._k, self._v = self._k.repeat_interleave(repeats, dim=0), self._v.repeat_interleave(repeats, dim=0)
+
+    def batch_select_indices(self, indices: torch.Tensor) -> None:
+        if self.get_seq_length() > 0:
+            self._k, self._v = self._k[indices, ...], self._v[indices, ...]
+
+    def advance(self, T: int) -> None:
+        pass
+
+    def reset(self) -> None:
+        self._k = self._v = None
+        self.is_initialized = False
+
+    def carried_tensors(self):
+        return [t for t in (self._k, self._v) if t is not None]
+
+    def import_carried(self, seen_tokens: int) -> None:
+        pass
+
+    def clone(self) -> "DynamicLayer":
+        new = copy.copy(self)
+        if self._k is not None:
+            new._k, new._v = self._k.clone(), self._v.clone()
+        return new
+
+    def copy_from(self, other: "DynamicLayer") -> None:
+        self._k = None if other._k is None else other._k.clone()
+        self._v = None if other._v is None else other._v.clone()
+        self.is_initialized = other.is_initialized
+
+
 class StaticCachePrealloc(_HFCache):
     """Aggregate cache: one pre-allocated layer object per decoder layer, dispatched by
     `config.layer_types` (std:366-443)."""
@@ -379,6 +474,8 @@ class StaticCachePrealloc(_HFCache):
                 layers.append(StaticLinearLayerPrealloc(config=cfg, batch_size=batch_size, device=device, dtype=dtype,
                                                         zero_init=zero_init,
                                                         recurrent_state_shape=recurrent_state_shape))
+            else:                                   # full attention: dynamic cache, as strm:548-550
+                layers.append(DynamicLayer())
         if _HFCache is not object:
             try:
                 super().__init__(layers=layers, offloading=offloading, offload_only_non_sliding=offload_only_non_sliding)

@@ -221,6 +221,41 @@ def test_module_parameter_names_match_reference_checkpoint_layout():
         assert ours == ref, (i, set(ours) ^ set(ref))
 
 
+def test_dynamic_layer_fallback_and_total_dispatch():
+    """strm:67-157, 548-550: a layer type that is neither sliding nor linear gets a growing K/V cache, so
+    `cache.layers[i]` exists for every decoder layer."""
+    from infinitevl_amd.cache import DynamicLayer, StaticCachePrealloc, StaticLinearLayerPrealloc, \
+        StaticSlidingWindowLayerPrealloc
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    cfg = InfiniteVLTextConfig(vocab_size=97, hidden_size=64, intermediate_size=96, num_hidden_layers=3,
+                               num_attention_heads=4, num_key_value_heads=2, head_dim=16, sliding_window=8,
+                               layer_types=["sliding_attention", "full_attention", "linear_attention"],
+                               num_linear_heads=4, num_linear_key_value_heads=4, linear_head_dim=16)
+    cache = StaticCachePrealloc(config=cfg, batch_size=1, device="cpu", dtype=torch.float32)
+    assert [type(layer) for layer in cache.layers] == [StaticSlidingWindowLayerPrealloc, DynamicLayer,
+                                                        StaticLinearLayerPrealloc]
+    dyn = cache.layers[1]
+    assert dyn.get_seq_length() == 0 and dyn.get_max_cache_shape() == -1
+    k1, v1 = torch.randn(1, 2, 5, 16), torch.randn(1, 2, 5, 16)
+    k2, v2 = torch.randn(1, 2, 3, 16), torch.randn(1, 2, 3, 16)
+    fk, fv = cache.update(1, k1, v1)
+    assert torch.equal(fk, k1) and dyn.get_seq_length() == 5
+    fk, fv = cache.update(1, k2, v2)
+    assert torch.equal(fk, torch.cat([k1, k2], -2)) and torch.equal(fv, torch.cat([v1, v2], -2))
+    assert dyn.get_mask_sizes(torch.arange(3)) == (8, 0)
+    twin = cache.clone().layers[1]
+    dyn.crop(6)
+    assert dyn.get_seq_length() == 6 and twin.get_seq_length() == 8 and torch.equal(dyn.keys, fk[..., :6, :])
+    dyn.crop(-2)
+    assert dyn.get_seq_length() == 4
+    dyn.batch_repeat_interleave(3)
+    assert dyn.keys.shape[0] == 3
+    dyn.batch_select_indices(torch.tensor([0]))
+    assert dyn.keys.shape[0] == 1
+    cache.reset()
+    assert dyn.get_seq_length() == 0
+
+
 def _tiny_cfg(z):
     from infinitevl_amd.harness import InfiniteVLTextConfig
     lt = [str(x) for x in z["layer_types"]]

@@ -836,3 +836,29 @@ def test_sequence_parallel_prefill_two_ranks_bit_exact():
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "sp_check.py")],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "SP_CHECK PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_full_attention_layer_with_dynamic_cache_equals_one_causal_call():
+    """A "full_attention" layer type (strm:548-550 fallback): the module goes through the growing DynamicLayer cache
+    and plain causal attention; two chunks fed through the cache == one call over the whole sequence."""
+    from infinitevl_amd.cache import DynamicLayer, StaticCachePrealloc
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    from infinitevl_amd.modules import InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
+    cfg = InfiniteVLTextConfig(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=1,
+                               num_attention_heads=2, num_key_value_heads=1, head_dim=128, sliding_window=16,
+                               layer_types=["full_attention"])
+    torch.manual_seed(4)
+    attn = InfiniteVLSelfAttention(cfg, 0).to(DEV, torch.bfloat16).eval()
+    rope = InfiniteVLRotaryEmbedding(cfg).to(DEV)
+    assert attn.sliding_window is None
+    x = bf(torch.randn(1, 150, 256) * 0.5).to(DEV)
+    pos = torch.arange(150, device=DEV)[None, None].expand(3, 1, 150).contiguous()
+    with torch.no_grad():
+        full, _ = attn(x, position_embeddings=rope(x, pos))
+        cache = StaticCachePrealloc(config=cfg, batch_size=1, device=DEV, dtype=torch.bfloat16)
+        assert isinstance(cache.layers[0], DynamicLayer)
+        a, _ = attn(x[:, :90], position_embeddings=rope(x[:, :90], pos[:, :, :90]), past_key_values=cache)
+        b, _ = attn(x[:, 90:], position_embeddings=rope(x[:, 90:], pos[:, :, 90:]), past_key_values=cache)
+    assert cache.get_seq_length() == 150
+    got = torch.cat([a, b], 1)
+    assert rms_rel(full.float().cpu(), got.float().cpu()) < 4e-3
