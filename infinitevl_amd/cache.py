@@ -97,6 +97,10 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         pass
 
     # ---- fast path used by InfiniteVLSelfAttention -----------------------------------------------
+    def _prev_cache(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Read-only chronological view of the cached keys / values (std:122-124)."""
+        return self.keys, self.values
+
     def attend(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, scaling: float,
                window: Optional[int]) -> torch.Tensor:
         """q [B,T,Hq,d], k_new/v_new [B,T,Hkv,d] (time-major, post-RoPE).  Attention over
