@@ -106,15 +106,26 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
     return q, k, v, g, beta, float(scale), initial_state, ht, o, (B, T, H, K, V)
 
 
+def _from_head_first(q, k, v, g, beta, cu_seqlens):
+    """fla's deprecated [B,H,T,.] layout (chunk.py:361-373): rearranged to the time-major layout the kernels read."""
+    if cu_seqlens is not None:
+        raise RuntimeError("Sequences with variable lengths are not supported for head-first mode")
+    q, k, v = (x.transpose(1, 2).contiguous() for x in (q, k, v))
+    g, beta = (x.transpose(1, 2).contiguous() for x in (g, beta))
+    return q, k, v, g, beta
+
+
 def fused_recurrent_gated_delta_rule(
     q, k, v, g, beta, scale=None, initial_state=None, output_final_state=False, cu_seqlens=None,
-    use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
+    head_first=False, use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
 ):
     """Token-recurrent gated delta rule (fla:ops/gated_delta_rule/fused_recurrent.py:218-335).
 
     q,k [B,T,H,K] bf16, v [B,T,H,V] bf16, g [B,T,H] fp32 log-decay, beta [B,T,H]; returns
     (o [B,T,H,V] bf16, final_state [B,H,K,V] fp32 or None).  `final_state_out` (extension) makes the
     kernel write the state straight into a caller tensor (fp32 or bf16, may alias initial_state)."""
+    if head_first:
+        q, k, v, g, beta = _from_head_first(q, k, v, g, beta, cu_seqlens)
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
     lib = _lib.load()
@@ -123,15 +134,17 @@ def fused_recurrent_gated_delta_rule(
         _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
         _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
         B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _stream(q)))
-    return o, ht
+    return (o.transpose(1, 2) if head_first else o), ht
 
 
 def chunk_gated_delta_rule(
     q, k, v, g, beta, scale=None, initial_state=None, output_final_state=False, cu_seqlens=None,
-    use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
+    head_first=False, use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
 ):
     """Chunkwise gated delta rule, chunk 64 (fla:ops/gated_delta_rule/chunk.py:272-392).  Same I/O
     as fused_recurrent_gated_delta_rule; any T >= 1."""
+    if head_first:
+        q, k, v, g, beta = _from_head_first(q, k, v, g, beta, cu_seqlens)
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
     lib = _lib.load()
@@ -144,7 +157,7 @@ def chunk_gated_delta_rule(
         _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
         _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
         B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _p(ws), ws.numel(), _stream(q)))
-    return o, ht
+    return (o.transpose(1, 2) if head_first else o), ht
 
 
 def gdn_gate(a: torch.Tensor, b: torch.Tensor, A_log: torch.Tensor, dt_bias: torch.Tensor):
@@ -169,7 +182,7 @@ class ShortConvolution(nn.Module):
     cached inputs are carried in (pip fla 0.4.0 / streaming semantics)."""
 
     def __init__(self, hidden_size: int, kernel_size: int, bias: bool = False, activation: Optional[str] = "silu",
-                 device=None, dtype=None, **_unused):
+                 use_fast_conv1d: Optional[bool] = True, device=None, dtype=None, **_unused):
         super().__init__()
         if bias:
             raise NotImplementedError("InfiniteVL uses conv_bias=False (configuration_infinitevl.py)")
@@ -181,6 +194,14 @@ class ShortConvolution(nn.Module):
         self.weight = nn.Parameter(torch.empty(hidden_size, 1, kernel_size, device=device, dtype=dtype))
         self.register_parameter("bias", None)
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def extra_repr(self) -> str:
+        return (f"{self.hidden_size}, {self.hidden_size}, kernel_size={self.kernel_size}, groups={self.hidden_size}, "
+                f"bias=False, activation={self.activation}")
+
+    @property
+    def state_size(self) -> int:                                         # convolution.py:295-297
+        return self.hidden_size * self.kernel_size[0]
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[torch.Tensor] = None,
                 output_final_state: bool = False, cu_seqlens: Optional[torch.Tensor] = None, **kwargs):

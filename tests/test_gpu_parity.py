@@ -118,6 +118,19 @@ def test_gdn_chunk_equals_recurrent_kernel_at_full_width():
     assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 5e-3 and rms_rel(s2.cpu(), s1.cpu()) < 5e-3
 
 
+def test_gdn_head_first_layout_equals_time_major():
+    """fla's deprecated head_first=True layout ([B,H,T,.], chunk.py:361-373) is accepted and rearranged."""
+    from infinitevl_amd import ops
+    q, k, v, g, beta, h0 = parity.gdn_inputs(5, 2, 70, 3)
+    qd, kd, vd, bd = (x.to(DEV, torch.bfloat16) for x in (q, k, v, beta))
+    gd = g.to(DEV)
+    for fn in (ops.chunk_gated_delta_rule, ops.fused_recurrent_gated_delta_rule):
+        o_tm, s_tm = fn(qd, kd, vd, gd, bd, output_final_state=True, use_qk_l2norm_in_kernel=True)
+        o_hf, s_hf = fn(qd.transpose(1, 2), kd.transpose(1, 2), vd.transpose(1, 2), gd.transpose(1, 2),
+                        bd.transpose(1, 2), None, None, True, None, True, True)       # positional, fla order
+        assert o_hf.shape == (2, 3, 70, 256) and torch.equal(o_hf.transpose(1, 2), o_tm) and torch.equal(s_hf, s_tm)
+
+
 def test_gdn_error_behaviour():
     from infinitevl_amd import ops
     z = torch.zeros(2, 4, 2, 128, dtype=torch.bfloat16, device=DEV)
