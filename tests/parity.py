@@ -146,11 +146,12 @@ def bf16_params(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3, window: int = 96,
-                 seed: int = 0, stream_T: int = 70, fuse: bool = False) -> Dict[str, float]:
+                 seed: int = 0, stream_T: int = 70, fuse: bool = False, heads: int = 2,
+                 noise_floor: bool = False) -> Dict[str, float]:
     """4-layer stack (1 SWA + 3 GDN), real head dims: prefill (chunk path) -> streaming frame (chunk path,
     carry-in conv, ring wrap) -> decode steps (recurrent path), HIP modules vs oracle with bf16 activations."""
     from infinitevl_amd.harness import InfiniteVLTextStack
-    hc, oc = small_configs(window)
+    hc, oc = small_configs(window, heads=heads)
     params = bf16_params(omodel.random_params(oc, seed=seed, vocab=hc.vocab_size))
     stack = InfiniteVLTextStack(hc)
     load_params(stack, params)
@@ -159,6 +160,9 @@ def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3
         stack.fuse_()          # fused projections + prologue/epilogue kernels
     cache = stack.allocate_inference_cache(1)
     ocache = omodel.new_cache(oc, cache_dtype=torch.bfloat16)
+    # noise_floor: a third run, the oracle with fp32 activations / no kernel rounding, to express both bf16 results
+    # (ours and the oracle's bf16 model) as distances from the exact arithmetic
+    xcache = omodel.new_cache(oc, cache_dtype=torch.float32) if noise_floor else None
     g_ = torch.Generator().manual_seed(seed + 1)
     res: Dict[str, float] = {}
     pos = 0
@@ -172,6 +176,10 @@ def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3
                          past_key_values=cache, logits_to_keep=0)
             torch.cuda.synchronize()
             res[name] = rms_rel(h_ref, h.float())
+            if noise_floor:
+                h_ex = omodel.text_stack(params, x, pid, oc, xcache, act_dtype=torch.float32, kernel_rounding=None)
+                res[name + "_vs_exact"] = rms_rel(h_ex, h.float())
+                res[name + "_bf16model_vs_exact"] = rms_rel(h_ex, h_ref)
             pos += T
     res["gdn_state"] = rms_rel(ocache[1].recurrent, cache.layers[1].recurrent_state.float())
     res["swa_keys"] = rms_rel(ocache[0].k, cache.layers[0].keys.float())
