@@ -442,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void gdn_chunk_prepare_kernel(
 // ==================================================================================================
 // (2) serial scan + output
 // ==================================================================================================
-constexpr int S_LDS = 136;     // bf16 per row of S^T  [32 cols][128 k]   (272 B)
-constexpr int S_LDV = 72;      // bf16 per row of v_new^T [32 cols][64 t] (144 B)
+constexpr int S_LDS = 128;     // bf16 per row of S^T  [32 cols][128 k]   (256 B, 16-byte pieces XOR-swizzled by the row)
+constexpr int S_LDV = 64;      // bf16 per row of v_new^T [32 cols][64 t] (128 B, pieces swizzled like the KdT image)
 constexpr int S_LDO = 40;      // bf16 per row of the output staging tile [64 t][32 cols] (80 B)
 
 // LDS operand image of one chunk (bytes).  Every region is an image of the workspace record region with the
@@ -591,7 +591,9 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       u32x2 w;
       w.x = pack2bf(S[4 * r4 + 0], S[4 * r4 + 1]);
       w.y = pack2bf(S[4 * r4 + 2], S[4 * r4 + 3]);
-      *(u32x2*)(s_st + l31 * S_LDS + 32 * wave + 8 * r4 + 4 * hi) = w;
+      // piece (k/8) = 4 wave + r4, stored at piece ^ (row & 15): the 16-row fragment reads below (ds_read_b128 lane
+      // groups {0-3,12-15,20-27}, ...) are then conflict-free; a padded 272-byte stride was not (33 % of the LDS cycles)
+      *(u32x2*)((unsigned char*)s_st + l31 * 256 + swz16(l31, 4 * wave + r4) + 8 * hi) = w;
     }
     dma_wait_all();                         // this wave's pieces of chunk ci have landed
     if (ci < 4) trace_stamp(trace, 40 + 4 * ci);
@@ -606,7 +608,8 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       aw[ks] = *(const u32x4*)(img + w_off + swz16(arow, 4 * ks + g4));
       aq[ks] = *(const u32x4*)(img + qh_off + swz16(arow, 4 * ks + g4));
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bs[ks][nt] = *(const u32x4*)(s_st + (16 * nt + l15) * S_LDS + 32 * ks + 8 * g4);
+      for (int nt = 0; nt < 2; ++nt)
+        bs[ks][nt] = *(const u32x4*)((const unsigned char*)s_st + (16 * nt + l15) * 256 + swz16(l15, 4 * ks + g4));
     }
     u32x2 uu[2];
 #pragma unroll
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
       u32x2 w;
       w.x = pack2bf(bflo(uu[nt].x) - accW[nt][0], bfhi(uu[nt].x) - accW[nt][1]);
       w.y = pack2bf(bflo(uu[nt].y) - accW[nt][2], bfhi(uu[nt].y) - accW[nt][3]);
-      *(u32x2*)(s_vn + (16 * nt + l15) * S_LDV + trow) = w;
+      *(u32x2*)((unsigned char*)s_vn + (16 * nt + l15) * 128 + swz8(16 * nt + l15, 2 * wave + (g4 >> 1)) + 8 * (g4 & 1)) = w;
 #pragma unroll
       for (int r = 0; r < 4; ++r) accQ[nt][r] *= eg[r];
     }
@@ -657,14 +660,15 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(
 
     // ---- (iii) state update (32x32 tile per wave) ; output rows 16w..16w+15: + Aqk v_new -------------------
     {
-      const bf16_t* vp = s_vn + l31 * S_LDV + 8 * hi;
+      const unsigned char* vp = (const unsigned char*)s_vn + l31 * 128;
       u32x4 vfr[4], bv[2][2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) vfr[ks] = *(const u32x4*)(vp + 16 * ks);
+      for (int ks = 0; ks < 4; ++ks) vfr[ks] = *(const u32x4*)(vp + swz8(l31, 2 * ks + hi));
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bv[k2][nt] = *(const u32x4*)(s_vn + (16 * nt + l15) * S_LDV + 32 * k2 + 8 * g4);
+        for (int nt = 0; nt < 2; ++nt)
+          bv[k2][nt] = *(const u32x4*)((const unsigned char*)s_vn + (16 * nt + l15) * 128 + swz8(16 * nt + l15, 4 * k2 + g4));
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(kd[ks]), mf(vfr[ks]), S, 0, 0, 0);
