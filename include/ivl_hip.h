@@ -30,6 +30,9 @@ extern "C" {
 
 #define IVL_ABI_VERSION 1
 
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
+#define IVL_API __attribute__((visibility("default")))
+
 /* element type codes for the arguments that accept more than one */
 #define IVL_BF16 0
 #define IVL_F16 1
@@ -42,8 +45,8 @@ extern "C" {
 #define IVL_ERR_WORKSPACE (-3)     /* workspace too small (see the *_workspace_bytes helpers)  */
 #define IVL_ERR_LAUNCH (-4)        /* hipLaunch / hipGetLastError failure                      */
 
-int ivl_abi_version(void);
-const char* ivl_last_error(void);
+IVL_API int ivl_abi_version(void);
+IVL_API const char* ivl_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Gated DeltaNet, token-recurrent form.
@@ -55,7 +58,7 @@ const char* ivl_last_error(void);
  * (IVL_F32 or IVL_BF16); ht may alias h0 (in-place state update: each element is read once, then
  * written once by the same thread).  Requires K == 128, V % 64 == 0.
  * ------------------------------------------------------------------------------------------- */
-int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+IVL_API int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
                           void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
                           int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream);
 
@@ -68,8 +71,8 @@ int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const flo
  * `workspace` holds the pre-pass results; size from ivl_gdn_chunk_workspace_bytes.
  * Requires K == 128, V == 256 (the InfiniteVL head shape), any T >= 1 (zero-padded last chunk).
  * ------------------------------------------------------------------------------------------- */
-size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V);
-int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+IVL_API size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V);
+IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
                       void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
                       int B, int T, int H, int K, int V, float scale, int use_qk_l2norm,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -79,7 +82,7 @@ int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* 
  * Replaces the torch glue at std:1293-1294.  a,b bf16 [rows,H] (a_proj / b_proj outputs);
  * A_log, dt_bias fp32 [H].
  * ------------------------------------------------------------------------------------------- */
-int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const float* dt_bias,
+IVL_API int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const float* dt_bias,
                      float* g, void* beta, int rows, int H, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -90,7 +93,7 @@ int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const flo
  * last.  state_in == NULL means zero history; state_out == NULL means "do not store";
  * state_out may alias state_in.  T == 1 is the decode step.  D % 8 == 0.
  * ------------------------------------------------------------------------------------------- */
-int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,
+IVL_API int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,
                        int B, int T, int D, int W, int apply_silu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -98,7 +101,7 @@ int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, 
  * Replaces fla.modules.FusedRMSNormGated.forward (call site std:1338;
  *   fla:modules/fused_norm_gate.py:27-95).  x, gate, y bf16 [rows,N]; weight bf16 [N].
  * ------------------------------------------------------------------------------------------- */
-int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
+IVL_API int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
                                int rows, int N, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -109,7 +112,7 @@ int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weig
  * (sum == d/2) pick the t/h/w table per channel block.  Products and the sum are each rounded to
  * bf16 like the reference's eager bf16 arithmetic (bit-identical result).
  * ------------------------------------------------------------------------------------------- */
-int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
+IVL_API int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
                   int B, int T, int Hq, int Hkv, int d, int s0, int s1, int s2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -148,17 +151,17 @@ typedef struct ivl_swa_args {
   size_t workspace_bytes;
 } ivl_swa_args;
 
-size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);
-int ivl_swa_fwd(const ivl_swa_args* args, void* stream);
+IVL_API size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);
+IVL_API int ivl_swa_fwd(const ivl_swa_args* args, void* stream);
 
 /* Append the T new tokens to the ring (slot (pos+t) % C) -- after ivl_swa_fwd of the same call.
  * Replaces the tail copy-back of std:146-172.  k_new,v_new bf16 with the strides given. */
-int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
+IVL_API int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
                          void* k_cache, void* v_cache, int B, int T, int Hkv, int d, int cache_capacity,
                          int64_t pos, const int64_t* pos_dev, void* stream);
 
 /* *counter += delta on the device (graph-replayable position bookkeeping). */
-int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
+IVL_API int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused prologue / epilogue entry points: the same arithmetic as the
@@ -170,7 +173,7 @@ int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
 /* 3 short convs (+SiLU, carry-in, state in/out as in ivl_short_conv_fwd) + gate math (ivl_gdn_gate_fwd).
  * proj bf16 [B*T, ld]; q|k|v|a|b start at columns col_*; outputs q [B,T,Dq], k [B,T,Dk], v [B,T,Dv] bf16
  * contiguous, g fp32 [B,T,H], beta bf16 [B,T,H]. */
-int ivl_gdn_prologue_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
+IVL_API int ivl_gdn_prologue_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
                          const void* w_q, const void* w_k, const void* w_v,
                          const void* sq_in, const void* sk_in, const void* sv_in,
                          void* sq_out, void* sk_out, void* sv_out,
@@ -180,29 +183,29 @@ int ivl_gdn_prologue_fwd(const void* proj, int64_t ld, int col_q, int col_k, int
 
 /* ivl_rmsnorm_swish_gate_fwd with the gate read in place: gate element (token, head, c) at
  * gate + token*gate_ld + head*N + c; x,y [rows = tokens*H, N] contiguous. */
-int ivl_rmsnorm_swish_gate_strided_fwd(const void* x, const void* gate, int64_t gate_ld, int H,
+IVL_API int ivl_rmsnorm_swish_gate_strided_fwd(const void* x, const void* gate, int64_t gate_ld, int H,
                                        const void* weight, void* y, int rows, int N, float eps, void* stream);
 
 /* ivl_mrope_fwd on column blocks of a fused qkv projection: q element (b,t,h,c) at
  * q + (b*T+t)*q_ld + h*d + c, k likewise with k_ld. */
-int ivl_mrope_strided_fwd(void* q, void* k, int64_t q_ld, int64_t k_ld, const void* cos, const void* sin,
+IVL_API int ivl_mrope_strided_fwd(void* q, void* k, int64_t q_ld, int64_t k_ld, const void* cos, const void* sin,
                           int B, int T, int Hq, int Hkv, int d, int s0, int s1, int s2, void* stream);
 
 /* Decoder-layer norm (std:1400-1420 / Qwen2RMSNorm) fused with the residual add:
  *   h = bf16(x + residual) -> h_out   (skipped when residual == NULL: h = x)
  *   y = bf16(weight * bf16(h * rsqrt(mean(h^2) + eps)));  x,residual,y,h_out bf16 [rows,N], N%8==0, N<=8192. */
-int ivl_add_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void* y, void* h_out,
+IVL_API int ivl_add_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void* y, void* h_out,
                         int rows, int N, float eps, void* stream);
 
 /* SwiGLU gate over a fused gate|up projection: y[r,i] = bf16(bf16(silu(gu[r,i])) * gu[r,I+i]) (std:945). */
-int ivl_silu_mul_fwd(const void* gate_up, void* y, int64_t rows, int I, void* stream);
+IVL_API int ivl_silu_mul_fwd(const void* gate_up, void* y, int64_t rows, int I, void* stream);
 
 /* Gated DeltaNet mixer core for ONE new token per sequence (GatedDeltaNet.forward, std:1215-1347, q_len == 1):
  * = ivl_gdn_prologue_fwd + ivl_gdn_recurrent_fwd(use_qk_l2norm=1) + ivl_rmsnorm_swish_gate_strided_fwd in one launch,
  * same rounding points.  proj [B, ld] bf16 is the fused projection row (columns col_q|col_k: H*128 each, col_v|col_g:
  * H*256 each, col_a|col_b: H each); conv weights [D,4] bf16; conv states [B,D,4] bf16 and the recurrent state
  * [B,H,128,256] (IVL_F32 / IVL_BF16) are updated IN PLACE; y [B, H*256] bf16 is the gated-norm output (o_proj input). */
-int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_g, int col_a,
+IVL_API int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_g, int col_a,
                             int col_b, const void* conv_wq, const void* conv_wk, const void* conv_wv,
                             void* conv_state_q, void* conv_state_k, void* conv_state_v, const float* A_log,
                             const float* dt_bias, const void* norm_weight, float eps, void* state, int state_dtype,
@@ -212,12 +215,12 @@ int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, int col_k, 
  * Replaces the q/k/v/o, GDN in/out, MLP and tied lm_head projections (std:1047-1054, 1215-1240, 945, 2091-2092)
  * when q_len == 1: a pure weight stream bounded by HBM.  x,W,bias,y bf16, row-major contiguous; fp32 accumulation;
  * bias may be NULL.  K % 8 == 0.  IVL_ERR_UNSUPPORTED for M > 4 (callers use a GEMM there). */
-int ivl_linear_small_m_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
+IVL_API int ivl_linear_small_m_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
 
 /* SwiGLU MLP head of a decode step (std:945: act_fn(gate_proj(x)) * up_proj(x)), fused gate|up weight [2I,K]:
  *   y[M,I] = bf16( bf16(silu(bf16(x Wg^T))) * bf16(x Wu^T) ),  Wg = w_gate_up[:I], Wu = w_gate_up[I:]
  * = ivl_linear_small_m_fwd on the fused weight followed by ivl_silu_mul_fwd, bit for bit.  bias [2I] or NULL. */
-int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, const void* bias, void* y, int M, int I, int K,
+IVL_API int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, const void* bias, void* y, int M, int I, int K,
                                   void* stream);
 
 #ifdef __cplusplus

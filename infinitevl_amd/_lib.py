@@ -51,11 +51,14 @@ class IvlError(RuntimeError):
 _lib = None
 
 
-def load() -> ctypes.CDLL:
-    """Load the shared object once and declare every prototype."""
+def load(path: str = None) -> ctypes.CDLL:
+    """Load the shared object once and declare every prototype.  `path` (developer tools only: the
+    instrumented build libivl_hip_trace.so) must be given before the first operator call."""
     global _lib
     if _lib is not None:
         return _lib
+    if path is not None:
+        globals()["LIB_PATH"] = path
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found. The MI355X kernels are mandatory (there is no CPU or PyTorch fallback): "

@@ -59,13 +59,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// ---- optional in-kernel timeline (debug): block (0,0,0), thread 0 stamps the shader clock ------
-// The buffer is set with ivl_debug_set_trace(); NULL (the default) compiles to one scalar branch.
-__device__ __forceinline__ void trace_stamp(long long* trace, int slot) {
-  if (trace != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    trace[slot] = (long long)__builtin_readcyclecounter();
-}
-long long* debug_trace_buffer();
+// ---- in-kernel timeline: DEVELOPER build only (`make trace` -> libivl_hip_trace.so, -DIVL_TRACE) ----------
+// The product library contains neither the clock reads nor the setter: every macro below compiles to nothing.
+// In the trace build a kernel keeps shader-clock readings in registers (IVL_T(name) declares/reads one) and
+// block (0,0,0) / thread 0 writes differences into the device buffer ONCE at the end (IVL_TOUT): no memory
+// traffic or extra vmcnt/lgkmcnt waits perturb the timed regions.  Each translation unit that traces owns a
+// device pointer, set by ivl_debug_set_trace through the per-unit setter.
+#ifdef IVL_TRACE
+#define IVL_TRACE_DECL(unit)                                                                      \
+  static __device__ long long* ivl_trace_buf = nullptr;                                            \
+  void trace_set_##unit(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ivl_trace_buf), &p, sizeof(p)); }
+#define IVL_T(name) const long long name = (long long)__builtin_readcyclecounter()
+#define IVL_TVAR(name) long long name = 0
+#define IVL_TACC(acc, t1, t0) acc += (t1) - (t0)
+#define IVL_TOUT(slot, value)                                                                      \
+  do {                                                                                             \
+    long long* tb_ = ivl_trace_buf;                                                                \
+    if (tb_ != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+      tb_[slot] = (long long)(value);                                                              \
+  } while (0)
+#else
+#define IVL_TRACE_DECL(unit)
+#define IVL_T(name) ((void)0)
+#define IVL_TVAR(name) ((void)0)
+#define IVL_TACC(acc, t1, t0) ((void)0)
+#define IVL_TOUT(slot, value) ((void)0)
+#endif
 
 // ---- host side -------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -16,9 +16,6 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static long long* g_trace = nullptr;
-long long* debug_trace_buffer() { return g_trace; }
-
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -266,9 +263,18 @@ static inline int grid_for(long long work_items, int block = 256, int cap = 256 
 using namespace ivl;
 
 extern "C" int ivl_abi_version(void) { return IVL_ABI_VERSION; }
-// Debug only (not part of the drop-in boundary): device buffer of >= 64 int64 slots that instrumented
-// kernels stamp with the shader clock at phase boundaries; NULL switches the timeline off.
-extern "C" void ivl_debug_set_trace(void* device_buffer) { ivl::g_trace = (long long*)device_buffer; }
+#ifdef IVL_TRACE
+// Developer build only (libivl_hip_trace.so, never shipped): device buffer of >= 64 int64 slots that the instrumented
+// kernels stamp with the shader clock at phase boundaries (NULL switches the timeline off), and the scan-geometry knob.
+namespace ivl {
+void trace_set_gdn(void* p);
+extern int g_scan_nw;
+}
+extern "C" IVL_API void ivl_debug_set_trace(void* device_buffer) {
+  ivl::trace_set_gdn(device_buffer);
+}
+extern "C" IVL_API void ivl_debug_set_scan_waves(int nw) { ivl::g_scan_nw = nw == 2 ? 2 : 4; }
+#endif
 extern "C" const char* ivl_last_error(void) { return g_err; }
 
 extern "C" int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,

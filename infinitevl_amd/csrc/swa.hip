@@ -38,7 +38,6 @@ struct SwaParams {
   long long pos; const long long* pos_dev;
   float scaling;
   float* part_o; float* part_ml;
-  long long* trace;
 };
 
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
@@ -242,17 +241,13 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
   };
 
-  trace_stamp(p.trace, 0);
   if (kt_begin < kt_end) load_tile(kt_begin);
   const float sc = p.scaling * LOG2E;
 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int ts = 1 + 5 * (kt - kt_begin);
-    if (kt - kt_begin < 6) trace_stamp(p.trace, ts);
     __syncthreads();
     store_tile();
     __syncthreads();
-    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 1);
 
     // ---- S^T = K Q^T : 4 key sub-tiles x 4 d-steps; d-step outermost so that consecutive MFMAs go to
     //      independent accumulators (no back-to-back dependent issue) -------------------------------------
@@ -277,7 +272,6 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     // next tile's global loads are issued behind the first MFMA batch (their address arithmetic no longer
     // delays it); they have the softmax + PV phases to land before store_tile of the next iteration
     if (kt + 1 < kt_end) load_tile(kt + 1);
-    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 2);
     // ---- band mask + online softmax (lane-local rows) -----------------------------------------
     // Interior tiles (every key visible to every row of this wave) skip the per-element band test.
     const int jbase = kt * SWA_KT + 4 * g;
@@ -335,8 +329,6 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
         pf[qg][ks2].w = pack2bf(sacc[qg][2 * ks2 + 1][2], sacc[qg][2 * ks2 + 1][3]);
       }
     }
-
-    if (kt - kt_begin < 6) trace_stamp(p.trace, ts + 3);
     // ---- O^T += V^T P^T : 8 d sub-tiles x 2 key-steps ------------------------------------------
     const unsigned char* vbase = smem + SWA_LDS_K;
 #pragma unroll
@@ -361,7 +353,6 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
   }
 
-  trace_stamp(p.trace, 40);
   // ---- epilogue: lane owns its rows, d = 16 mt2 + 4g + r ----------------------------------------
 #pragma unroll
   for (int qg = 0; qg < QG; ++qg) {
@@ -490,15 +481,7 @@ __global__ __launch_bounds__(256) void swa_cache_append_kernel(
 // 16-row query groups per wave.  128-row workgroups halve the LDS traffic per MFMA (1.4x per-tile efficiency) but
 // also halve the number of workgroups: they pay once a call still offers >= 4 workgroups per CU (B*T*Hq >= 128K rows);
 // below that the finer 64-row granularity balances the causal triangle better (measured: T=4096 118 vs 132 us).
-static int swa_qg(int B, int T, int Hq) {
-  static int force = -1;
-  if (force < 0) {
-    const char* e = getenv("IVL_SWA_QG");     // debug override: 1 or 2
-    force = e ? atoi(e) : 0;
-  }
-  if (force == 1 || force == 2) return force;
-  return (long long)B * T * Hq >= 131072 ? 2 : 1;
-}
+static int swa_qg(int B, int T, int Hq) { return (long long)B * T * Hq >= 131072 ? 2 : 1; }
 
 static int swa_base_nsplit(int B, int T, int Hq) {
   const int qt = SWA_QT * swa_qg(B, T, Hq);
@@ -556,7 +539,6 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.B = a->B; p.T = a->T; p.T_new = a->T_new; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity; p.W = a->window;
   p.nsplit = nsplit; p.pos = a->pos; p.pos_dev = (const long long*)a->pos_dev; p.scaling = a->scaling;
   p.part_o = nullptr; p.part_ml = nullptr;
-  p.trace = debug_trace_buffer();
   if (nsplit > 1) {
     const size_t n_o = (size_t)a->B * nsplit * a->T * a->Hq * SWA_D;
     const size_t need = (n_o + (size_t)a->B * nsplit * a->T * a->Hq * 2) * sizeof(float);

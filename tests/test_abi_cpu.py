@@ -38,6 +38,20 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.ivl_abi_version() == 1
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """`nm -D` of the product library == the prototypes of include/ivl_hip.h: no debug hooks, no C++ symbols."""
+    import subprocess
+    from infinitevl_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    hdr = open(os.path.join(ROOT, "include", "ivl_hip.h")).read()
+    declared = set(re.findall(r"^IVL_API [^\n(]*?\b(ivl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert exported == declared, exported ^ declared
+    src = "".join(open(os.path.join(ROOT, "infinitevl_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "infinitevl_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert "getenv" not in src, "no environment knobs on the launch path"
+
+
 def test_argument_validation_returns_codes(lib):
     from infinitevl_amd import _lib
     rc = lib.ivl_short_conv_fwd(None, None, None, None, None, 1, 1, 8, 4, 1, None)
@@ -68,7 +82,7 @@ def test_argument_validation_returns_codes(lib):
 
 
 def test_workspace_sizes(lib):
-    per_chunk = 91136
+    per_chunk = 66560          # 64 MFMA fragment blocks of 1 KB + e^gamma / beta block
     assert lib.ivl_gdn_chunk_workspace_bytes(1, 256, 16, 128, 256) == 16 * 4 * per_chunk
     assert lib.ivl_gdn_chunk_workspace_bytes(2, 65, 3, 128, 256) == 2 * 3 * 2 * per_chunk
     # long calls are processed in 64-chunk segments: bounded workspace + fp32 state carry
