@@ -7,21 +7,25 @@
 //        q_hat, k_hat = l2norm -> bf16;  gamma = cumsum(g);  L = tril(bf16(beta k_hat) k_hat^T, -1);
 //        Tw = (I+L)^-1 in fp32 (16x16 diagonal blocks by column-parallel substitution in registers, the rest by
 //        block elimination on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32, intermediates chained in registers);
-//        Tu = Tw * e^{gamma_i-gamma_j};  w = bf16(Tw) bf16(beta k_hat);  A = tril((q_hat k_hat^T) * Gamma).
-//      It leaves one 65 KB record per chunk holding the five A-operand matrices of the serial pass, already
-//      decayed / negated and stored as a sequence of 1 KB MFMA FRAGMENT BLOCKS (below), plus e^gamma and beta.
+//        Tu = Tw * e^{gamma_i-gamma_j};  w = bf16(Tw) bf16(beta k_hat);  u = bf16(Tu) bf16(beta v);
+//        A = tril((q_hat k_hat^T) * Gamma).
+//      It leaves one 89 KB record per chunk holding the four A-operand matrices of the serial pass, already
+//      decayed / negated and stored as a sequence of 1 KB MFMA FRAGMENT BLOCKS (below), e^gamma, and u in the
+//      accumulator layout of the scan.
 //  (2) gdn_chunk_scan_kernel -- SERIAL over chunks.  One WAVE owns a 16-column slab of the state for all 128
 //      rows: S[128 x 16] fp32 lives in 32 accumulator registers for the whole call and never visits LDS.  The
 //      MFMA C layout (lane = column, registers = rows) IS the B-operand layout of the next product once the
 //      contraction index is permuted inside each block of 32 (slot 8g+e <-> index 4g+e | 16+4g+(e-4)); the
 //      records are written with that permutation, so per chunk a wave runs
-//          u      = Tu (beta v)                  ( 8 MFMA, beta v from an LDS transpose read of the raw v slab)
-//          v_new  = u - (w e^gamma) S            (16 MFMA, S as B operand straight from the accumulators)
+//          v_new  = u - (w e^gamma) S            (16 MFMA, u as C input, S as B operand straight from the accumulators)
 //          S      = e^{gamma_L} S + (k_hat e^{gamma_L-gamma})^T v_new      (16 MFMA, v_new straight from accumulators)
-//          o^T    = scale ((S^T q_hat^T) e^gamma + v_new^T A^T)            (24 MFMA, transposed: 8-byte row stores)
-//      with no barrier and no LDS traffic on the S -> v_new -> S chain.  The 4 waves of a workgroup share the
-//      chunk's operand image, which arrives by LDS-DMA (global_load_lds_dwordx4, four 1 KB pieces per issue)
-//      into one of two alternating images; one barrier per chunk.
+//          o^T    = scale ((S^T q_hat^T) e^gamma + v_new^T A^T)            (22 MFMA, transposed: 8-byte row stores)
+//      with no LDS traffic on the S -> v_new -> S chain.  A workgroup = 4 such compute waves (64 state columns)
+//      + 2 LOADER waves that do nothing but stream the chunks' operand images into LDS by LDS-DMA
+//      (global_load_lds_dwordx4, four 1 KB pieces per issue): the ~64 cycles a wave is held per DMA piece
+//      (the CU's 64 B/clk vector-memory path) never stall a wave that feeds the matrix pipe.  The image is split
+//      in two halves by phase (H1: Wn, q_hat, e^gamma, u slab; H2: Kd^T, Aqk), each double buffered and refilled
+//      right after its last reader's barrier: 1.5 chunks of prefetch distance with two barriers per chunk.
 //
 // Fragment block (v_mfma_f32_16x16x32_bf16): 16 rows x 32 contraction slots = 64 x 16 bytes, piece (g, i) at byte
 // 16 (16 g + i) holds row i, slots 8g..8g+7  <->  contraction indices 4g+e (e < 4), 16+4g+(e-4) (e >= 4).  A wave
@@ -43,16 +47,16 @@ constexpr int GK = 128;       // key head dim
 constexpr int GV = 256;       // value head dim
 constexpr int G_SEG_CHUNKS = 64;   // chunks per workspace segment (4096 tokens)
 
-// ---- workspace record per (batch*head, chunk): byte offsets; [0, 65536) is a sequence of 64 fragment blocks ----
+// ---- workspace record per (batch*head, chunk): byte offsets; [0, 57344) is a sequence of 56 fragment blocks ----
 constexpr int REC_WN = 0;          // -bf16(bf16(w) e^gamma)       blocks (m, s)  = 4 m + s    rows: time   contraction: k
 constexpr int REC_QH = 16384;      // q_hat                        blocks (m, s)  = 4 m + s    rows: time   contraction: k
 constexpr int REC_KDT = 32768;     // (k_hat e^{gl-gamma})^T       blocks (t, s2) = 2 t + s2   rows: k      contraction: time
 constexpr int REC_AQK = 49152;     // tril((q k^T) Gamma)          blocks (m, s2) = 2 m + s2   rows: time   contraction: time
-constexpr int REC_TU = 57344;      // bf16(Tw e^{gamma_i-gamma_j}) blocks (m, s2) = 2 m + s2   rows: time   contraction: time
-constexpr int REC_EG = 65536;      // f32 e^gamma[64]
+constexpr int REC_EG = 57344;      // f32 e^gamma[64]
 constexpr int REC_EGL = REC_EG + 256;    // f32 e^gamma_last
-constexpr int REC_BETA = REC_EG + 512;   // f32 beta[64]
-constexpr size_t REC_STRIDE = 66560;     // 65 pieces of 1 KB
+constexpr int REC_U = 58368;       // bf16 u in the scan's accumulator layout: 8-byte piece ((slab, m, g), j) at
+                                   //   ((16 slab + 4 m + g) * 16 + j) * 8 = u[16m + 4g + 0..3][16 slab + j]   (32 KB)
+constexpr size_t REC_STRIDE = 91136;     // 89 pieces of 1 KB
 
 __device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) {
   mfma_bf16x8 r;
@@ -69,12 +73,18 @@ __device__ __forceinline__ u32x4 pack8(float a0, float a1, float a2, float a3, f
 // ==================================================================================================
 constexpr int P_LDK = 136;                         // bf16 elements per row of k_hat / q_hat / beta k_hat (272 B)
 constexpr int P_LDF = 68;                          // f32 elements per row of L / T
+constexpr int P_LDV = 264;                         // bf16 elements per row of beta v (528 B)
+constexpr int P_LDT = 72;                          // bf16 elements per row of Tu (144 B)
 constexpr int P_KH = 0;                            // k_hat            [64][136] bf16
 constexpr int P_QH = P_KH + GC * P_LDK * 2;        // q_hat            [64][136]
+constexpr int P_VB = 0;                            // bf16(beta v)     [64][264] row-major, written over k_hat / q_hat once
+                                                   //   they are dead (B operands via the LDS transpose read)
 constexpr int P_KB = P_QH + GC * P_LDK * 2;        // bf16(beta k_hat) [64][136]
 constexpr int P_L = P_KB + GC * P_LDK * 2;         // L, inverted IN PLACE to T = (I+L)^-1   [64][68] f32
-constexpr int P_SM = P_L + GC * P_LDF * 4;         // gam[64], eg[64], dec[64]
-constexpr int P_BYTES = P_SM + 4 * GC * 4;         // 70,656: two workgroups per CU
+constexpr int P_TU = P_L + GC * P_LDF * 4;         // bf16(Tu)         [64][72]
+constexpr int P_SM = P_TU + GC * P_LDT * 2;        // gam[64], eg[64], dec[64], beta[64]
+constexpr int P_BYTES = P_SM + 4 * GC * 4;         // 79,872: two workgroups per CU
+static_assert(GC * P_LDV * 2 <= 2 * GC * P_LDK * 2, "beta v must fit in the k_hat / q_hat region");
 static_assert(2 * P_BYTES <= 160 * 1024, "pre-pass LDS budget (2 workgroups per CU)");
 
 // sum over the 16 lanes of a DPP row (the 16 threads that share one q / k row), result in every lane
@@ -109,16 +119,19 @@ __device__ __forceinline__ u32x4 frag_tr32(const bf16_t* X, int ld, int k0, int 
 }
 
 __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
   bf16_t* s_kb = (bf16_t*)(smem + P_KB);
+  bf16_t* s_vb = (bf16_t*)(smem + P_VB);
   float* s_L = (float*)(smem + P_L);          // L, then T in place
+  bf16_t* s_tu = (bf16_t*)(smem + P_TU);
   float* s_gam = (float*)(smem + P_SM);
   float* s_eg = s_gam + GC;
   float* s_dec = s_eg + GC;
+  float* s_beta = s_dec + GC;
 
   IVL_T(tp0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,6 +157,15 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     qraw[rr] = *(const u32x4*)(q + tok * GK + 8 * oct);
     braw[rr] = beta[tok];
   }
+  u32x4 vraw[8];                                     // waves 4-7: the chunk's v tile, 8 x 16 bytes per thread (rows vr + 8 i)
+  const int t2v = tid - 256, voct = t2v & 31, vr = t2v >> 5;
+  if (wave_u >= 4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(vr + 8 * i, nvalid - 1);
+      vraw[i] = *(const u32x4*)(v + (((size_t)b * T + t0 + row) * H + h) * GV + 8 * voct);
+    }
+  }
   // ---- P1a (wave 0): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta ---------------
   if (wave_u == 0) {
     const size_t tok = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
@@ -161,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     s_gam[lane] = gv;
     s_eg[lane] = e;
     s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
+    s_beta[lane] = bv;                               // 0 for padded rows
     ((float*)(rec + REC_EG))[lane] = e;
-    ((float*)(rec + REC_BETA))[lane] = bv;
     if (lane == 0) *(float*)(rec + REC_EGL) = __expf(gl);
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
@@ -272,14 +294,9 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       *(u32x4*)(blk + ((hi + 2 * p) * 16 + (l31 & 15)) * 16) =
           pack8(val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p], val[10 + 4 * p], val[11 + 4 * p]);
   } else {
-    // blocks (m < 2, s2 = 1) of Aqk and Tu lie strictly above the diagonal: zeros
+    // blocks (m < 2, s2 = 1) of Aqk lie strictly above the diagonal: zeros
     const int t2 = tid - 384;                        // 0..127
-#pragma unroll
-    for (int z = 0; z < 2; ++z) {
-      const int idx = t2 + 128 * z;                  // 0..255: (matrix, m, piece)
-      const int mat = idx >> 7, m = (idx >> 6) & 1, pc = idx & 63;
-      *(u32x4*)(rec + (mat ? REC_TU : REC_AQK) + (2 * m + 1) * 1024 + pc * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
+    *(u32x4*)(rec + REC_AQK + (2 * (t2 >> 6) + 1) * 1024 + (t2 & 63) * 16) = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int z = 0; z < 4; ++z) copy_piece(t2 + 128 * z);                 // QH pieces 0..511
   }
@@ -315,8 +332,18 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 #pragma unroll
     for (int z = 0; z < 6; ++z) copy_piece(512 + t2 + 256 * z);           // QH 512..1023, KDT 1024..2047
   }
-  __syncthreads();                                   // B3
+  __syncthreads();                                   // B3: k_hat / q_hat are dead from here on
   IVL_T(tp3a);
+  if (wave_u >= 4) {                                 // bf16(beta v) row-major over the dead region (read after B7)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = vr + 8 * i;
+      const u32x4 vv = vraw[i];
+      const float bt = s_beta[row];
+      *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
+          pack8(bflo(vv.x) * bt, bfhi(vv.x) * bt, bflo(vv.y) * bt, bfhi(vv.y) * bt, bflo(vv.z) * bt, bfhi(vv.z) * bt, bflo(vv.w) * bt, bfhi(vv.w) * bt);
+    }
+  }
   // level 1: X[hb][lb] = -D_hb (L[hb][lb] D_lb) for the block pairs (1,0) and (3,2); the intermediate product stays in
   //          the accumulator registers: with the contraction order k = 4g + s (lane group g, instruction s) register s
   //          of a 16x16x4 result IS the B operand of instruction s of the next product.
@@ -374,23 +401,21 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();                                   // B6: T complete
   IVL_T(tp3);
 
-  // ---- P4a: Tu = Tw * e^{gamma_i - gamma_j} -> bf16 fragment blocks, one 16-byte piece per thread ------------------
+  // ---- P4a: Tu = Tw * e^{gamma_i - gamma_j} -> bf16, row-major LDS tile (8 elements per thread) ---------------------
   {
-    const int i = tid & 15, gg = (tid >> 4) & 3, blk = tid >> 6, m = blk >> 1, s2 = blk & 1;
-    if (!(m < 2 && s2 == 1)) {                       // those two blocks were zero-filled above
-      const int row = 16 * m + i, c0 = 32 * s2 + 4 * gg;
-      const float gi = s_gam[row];
-      float tv[8];
+    const int row = tid >> 3, c0 = 8 * (tid & 7);
+    const float gi = s_gam[row];
+    float tv[8];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const f32x4 tq = *(const f32x4*)(s_L + row * P_LDF + c0 + 16 * hh);
-        const f32x4 gj = *(const f32x4*)(s_gam + c0 + 16 * hh);
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 tq = *(const f32x4*)(s_L + row * P_LDF + c0 + 4 * hh);
+      const f32x4 gj = *(const f32x4*)(s_gam + c0 + 4 * hh);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) tv[4 * hh + c] = row >= c0 + 16 * hh + c ? tq[c] * __expf(gi - gj[c]) : 0.f;
-      }
-      *(u32x4*)(rec + REC_TU + tid * 16) = pack8(tv[0], tv[1], tv[2], tv[3], tv[4], tv[5], tv[6], tv[7]);
+      for (int c = 0; c < 4; ++c) tv[4 * hh + c] = row >= c0 + 4 * hh + c ? tq[c] * __expf(gi - gj[c]) : 0.f;
     }
+    *(u32x4*)(s_tu + row * P_LDT + c0) = pack8(tv[0], tv[1], tv[2], tv[3], tv[4], tv[5], tv[6], tv[7]);
   }
+  __syncthreads();                                   // B7: Tu and beta v complete
   // ---- P4b: w^T = kb^T Tw^T  (transposed so that a lane owns a time row and 32 k-columns): wave -> 32x32 tile
   //           (time tile mi, k tile s);  Wn = -bf16(bf16(w) e^gamma_i) -> fragment blocks ---------------------------
   {
@@ -418,6 +443,34 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
           pack8(bf_round(acc[4 * p]) * negeg, bf_round(acc[4 * p + 1]) * negeg, bf_round(acc[4 * p + 2]) * negeg, bf_round(acc[4 * p + 3]) * negeg,
                 bf_round(acc[8 + 4 * p]) * negeg, bf_round(acc[9 + 4 * p]) * negeg, bf_round(acc[10 + 4 * p]) * negeg, bf_round(acc[11 + 4 * p]) * negeg);
   }
+  // ---- P4c: u = Tu (beta v): wave -> 32 value columns, both 32-row time tiles; a lane owns one column and, per
+  //           group of four accumulator registers, four consecutive times = one 8-byte piece of the scan's layout ---
+  {
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 bfr = frag_tr32(s_vb, P_LDV, 16 * ks, 32 * wave_u, lane);       // (beta v)[time 16ks + 8hi + e][col 32w + l31]
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (ks > 2 * mi + 1) continue;               // Tu is lower triangular
+        const u32x4 tuf = *(const u32x4*)(s_tu + (32 * mi + l31) * P_LDT + 16 * ks + 8 * hi);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(tuf), mf(bfr), acc[mi], 0, 0, 0);
+      }
+    }
+    const int col = 32 * wave_u + l31;
+    unsigned char* ub = rec + REC_U + (size_t)(col >> 4) * 2048 + (col & 15) * 8;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {                  // times 32 mi + 8 a + 4 hi + 0..3  ->  m = 2 mi + (a >> 1), g = 2 (a & 1) + hi
+        const int m = 2 * mi + (a >> 1), gg = 2 * (a & 1) + hi;
+        *(u32x2*)(ub + (4 * m + gg) * 128) = u32x2{pack2bf(acc[mi][4 * a], acc[mi][4 * a + 1]), pack2bf(acc[mi][4 * a + 2], acc[mi][4 * a + 3])};
+      }
+  }
   IVL_T(tp4);
   IVL_TOUT(0, tp0); IVL_TOUT(1, tp1 - tp0); IVL_TOUT(2, tp2 - tp1); IVL_TOUT(3, tp3a - tp2); IVL_TOUT(4, tp3b - tp3a);
   IVL_TOUT(5, tp3 - tp3b); IVL_TOUT(6, tp4 - tp3); IVL_TOUT(7, tp4);
@@ -426,12 +479,17 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 // ==================================================================================================
 // (2) serial scan + output
 // ==================================================================================================
-constexpr int IMG_V = 66560;                               // per-wave raw v slab [64 t][16 cols] bf16 (2 KB each) follows the record image
-__host__ __device__ constexpr int img_bytes(int nw) { return IMG_V + nw * 2048; }
+// LDS: two images of 65 KB.  Image bytes [0, 58368) mirror the record (Wn, q_hat, Kd^T, Aqk, e^gamma); the workgroup's
+// 8 KB slab of u follows.  H1 = {Wn, q_hat, e^gamma, u slab} is read in the first half of a chunk, H2 = {Kd^T, Aqk} in
+// the second.
+constexpr int IMG_U = REC_U;                               // NCW compute waves x 2 KB
+constexpr int IMG_BYTES = IMG_U + 8192;                    // 66,560
+constexpr int SCAN_LDS = 2 * IMG_BYTES;                    // 133,120
+static_assert(SCAN_LDS <= 160 * 1024, "scan LDS budget");
 
 // LDS-DMA, four consecutive 1 KB pieces: global [gsrc + 1024 p + 16 lane] -> LDS [lds_dst + 1024 p + 16 lane], p = 0..3
 // (the instruction offset is added to both addresses).  gsrc and lds_dst are wave-uniform (SGPRs); hipcc does not count
-// these operations: completion is awaited with an explicit s_waitcnt vmcnt and published by the following barrier.
+// these operations: completion is awaited with explicit counted s_waitcnt vmcnt and published by the following barrier.
 __device__ __forceinline__ void dma4(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
   unsigned int keep;
   asm volatile(
@@ -445,55 +503,180 @@ __device__ __forceinline__ void dma4(const unsigned char* gsrc, unsigned int lds
       "s_mov_b32 m0, %0"
       : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
 }
-// one piece with per-lane source addresses
-__device__ __forceinline__ void dma1(const unsigned char* gsrc_lane, unsigned int lds_dst) {
+__device__ __forceinline__ void dma1(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
   unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
 }
 // workgroup barrier that waits for this wave's LDS traffic only (no vector-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void gdn_chunk_scan_kernel(
-    const unsigned char* __restrict__ ws, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+// Loader wave L (0 / 1) issues every other DMA statement of a half image.
+//   H1(ci): 4 x dma4 Wn, 4 x dma4 q_hat, 2 x dma4 u slab, 1 piece e^gamma  -> L0: 5 dma4 + 1 = 21 pieces, L1: 5 dma4 = 20
+//   H2(ci): 4 x dma4 Kd^T, 2 x dma4 Aqk                                    -> 12 pieces each
+template <int L, int NCW>
+__device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, int slab_wg, unsigned int lane16) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dma4(rec + REC_WN + (2 * q + L) * 4096, img + (unsigned int)(REC_WN + (2 * q + L) * 4096), lane16);      // Wn | q_hat: 8 groups of 4 KB
+  }
+  if (NCW == 4) dma4(rec + REC_U + slab_wg * 8192 + L * 4096, img + (unsigned int)(IMG_U + L * 4096), lane16);
+  else if (L == 1) dma4(rec + REC_U + slab_wg * 4096, img + (unsigned int)IMG_U, lane16);
+  if (L == 0) dma1(rec + REC_EG, img + (unsigned int)REC_EG, lane16);
+}
+template <int L>
+__device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int img, unsigned int lane16) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    dma4(rec + REC_KDT + (2 * q + L) * 4096, img + (unsigned int)(REC_KDT + (2 * q + L) * 4096), lane16);              // Kd^T | Aqk: 6 groups of 4 KB
+}
+
+// Barrier protocol (every wave of the workgroup executes the same sequence P, T(0), M(0), T(1), M(1), ...):
+//   P     : H1(0) has landed
+//   T(ci) : H2(ci) has landed;  every wave has finished chunk ci - 1      -> H2(ci + 1) may be issued (image (ci+1) & 1)
+//   M(ci) : H1(ci + 1) has landed;  every wave has read H1(ci)            -> H1(ci + 2) may be issued (image ci & 1)
+// so each half image is requested one whole chunk before its barrier.  vmcnt retires in issue order: "landed" = at most
+// the pieces issued AFTER the awaited half are still outstanding.
+template <int L, int NCW>
+__device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, int slab_wg, unsigned int lds0, unsigned int lane16) {
+  // pieces per half image and loader: H1 = 16 (Wn, q_hat) + u slab + e^gamma, H2 = 12
+  constexpr int N1 = NCW == 4 ? (L == 0 ? 21 : 20) : (L == 0 ? 17 : 20), N2 = 12;
+  auto wait_le = [&](int n) {                                   // s_waitcnt vmcnt(n), n a compile-time constant per call site
+    if (n == N1 + N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1 + N2) : "memory");
+    else if (n == N1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
+    else if (n == N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto rec = [&](int ci) { return ws_bh + (size_t)ci * REC_STRIDE; };
+  auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * IMG_BYTES); };
+  load_h1<L, NCW>(rec(0), img(0), slab_wg, lane16);
+  load_h2<L>(rec(0), img(0), lane16);
+  if (nt_seg > 1) {
+    load_h1<L, NCW>(rec(1), img(1), slab_wg, lane16);
+    wait_le(N1 + N2);                                           // H2(0) + H1(1) behind H1(0)
+  } else {
+    wait_le(N2);                                                // H2(0) behind H1(0)
+  }
+  lds_barrier();                                               // P
+  for (int ci = 0; ci < nt_seg; ++ci) {
+    if (ci + 1 < nt_seg) wait_le(N1);                           // H1(ci+1) behind H2(ci)
+    else wait_le(0);
+    lds_barrier();                                             // T(ci)
+    if (ci + 1 < nt_seg) {
+      load_h2<L>(rec(ci + 1), img(ci + 1), lane16);
+      wait_le(N2);                                             // H2(ci+1) behind H1(ci+1)
+    }
+    lds_barrier();                                             // M(ci)
+    if (ci + 2 < nt_seg) load_h1<L, NCW>(rec(ci + 2), img(ci + 2), slab_wg, lane16);
+  }
+}
+
+// Workgroup = NCW state waves + NCW output waves + 2 loader waves; pair w owns state columns v0..v0+15.
+//   state wave  : S (accumulators), per chunk  sb = bf16(S) -> LDS | T | v_new = u + Wn sb -> LDS | M | S = egl S + Kd^T v_new
+//   output wave : per chunk                                         T | (q_hat sb)^T e^gamma    | M | + v_new^T Aqk^T, store o
+// A single wave issues at most one instruction per ~4-5 cycles, and a chunk needs ~290 of them per slab: split over two
+// waves of the same SIMD the serial S -> v_new -> S chain carries 32 MFMAs + the conversions only, the other 22 MFMAs, the
+// scaling and the stores run beside it.  sb / v_new cross through 6 KB of LDS per pair, ordered by the two barriers the
+// loader protocol needs anyway.  NCW = 4: 64 columns per workgroup (operand image shared by four pairs: least L2 traffic);
+// NCW = 2: 32 columns, twice the workgroups -- used while the grid would otherwise leave most of the chip idle.
+constexpr int XCH_SB = SCAN_LDS;                            // per pair: sb 4 KB (4 fragments) | v_new 2 KB (2 fragments)
+__host__ __device__ constexpr int scan_lds_bytes(int ncw) { return SCAN_LDS + ncw * 6144; }
+static_assert(scan_lds_bytes(4) <= 160 * 1024, "scan LDS budget");
+
+template <int NCW>
+__global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
+    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
     int T, int H, int t_seg0, int nt_seg, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int IMG = img_bytes(NW);
 
   IVL_T(ts0);
-  IVL_TVAR(t_wait); IVL_TVAR(t_issue); IVL_TVAR(t_comp);
+  IVL_TVAR(t_bar); IVL_TVAR(t_bar2); IVL_TVAR(t_h1); IVL_TVAR(t_h2); IVL_TVAR(t_sb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int j = lane & 15, g = lane >> 4;
-  // grid = (B*H, 16/NW): linear block id = bh + B*H*slab, so with B*H % 8 == 0 all slabs of one head run on the same
-  // XCD (id % 8) and share its L2 for the record they all read.
+  // grid = (B*H, 16/NCW): linear block id = bh + B*H*slab, so with B*H % 8 == 0 all column slabs of one head run on
+  // the same XCD (id % 8) and share its L2 for the record they all read.
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh % H;
-  const int v0 = (blockIdx.y * NW + wave_u) * 16;               // first state column of this wave
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)smem);
   const unsigned int lane16 = lane * 16;
+  const unsigned char* ws_bh = ws + (size_t)bh * nt_seg * REC_STRIDE;
 
-  auto issue = [&](int ci) {                                    // stage chunk ci into image ci & 1
-    const unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * REC_STRIDE;
-    const unsigned int img = lds0 + (unsigned int)((ci & 1) * IMG);
-#pragma unroll
-    for (int qq = 0; qq < 16 / NW; ++qq) {
-      const int grp = qq * NW + wave_u;                         // 4 KB groups of the 64 KB operand part
-      dma4(rec + grp * 4096, img + (unsigned int)(grp * 4096), lane16);
-    }
-    if (wave_u == 0) dma1(rec + REC_EG + lane16, img + (unsigned int)REC_EG);
-    const int tc = t_seg0 + ci * GC;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {                               // raw v slab: token 32p + lane/2, 16-byte half lane&1
-      const int tok = min(tc + 32 * p + (lane >> 1), T - 1);
-      const bf16_t* src = v + (((size_t)b * T + tok) * H + h) * GV + v0 + 8 * (lane & 1);
-      dma1((const unsigned char*)src, img + (unsigned int)(IMG_V + wave_u * 2048 + p * 1024));
-    }
-  };
-  issue(0);
+  if (wave_u >= 2 * NCW) {                                      // ---- loader waves ----
+    if (wave_u == 2 * NCW) scan_loader<0, NCW>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    else scan_loader<1, NCW>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    return;
+  }
+  const int pair = wave_u < NCW ? wave_u : wave_u - NCW;
+  const int v0 = (blockIdx.y * NCW + pair) * 16;                // first state column of this pair
+  unsigned char* xsb = smem + XCH_SB + pair * 6144;             // sb: 4 fragments x 1 KB, lane-linear
+  unsigned char* xvn = xsb + 4096;                              // v_new: 2 fragments
+  auto frag = [&](const unsigned char* im, int off, int idx) { return *(const u32x4*)(im + off + idx * 1024 + lane16); };
 
+  if (wave_u >= NCW) {
+    // =========================== output wave ===========================
+    u32x4 fq[16];
+    float egv[4];
+    lds_barrier();                       // P: H1(0) has landed
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fq[i] = frag(smem, REC_QH, i);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(smem + REC_EG + (16 * m + j) * 4);
+    bf16_t* orow = o + (((size_t)b * T + t_seg0 + j) * H + h) * GV + v0 + 4 * g;
+    const size_t ostep = (size_t)16 * H * GV;                   // 16 tokens further
+    for (int ci = 0; ci < nt_seg; ++ci) {
+      const unsigned char* img = smem + (ci & 1) * IMG_BYTES;
+      const unsigned char* img_next = smem + ((ci + 1) & 1) * IMG_BYTES;
+      const int tc0 = t_seg0 + ci * GC;
+      lds_barrier();                     // T(ci): sb(ci) published, H2(ci) landed
+      u32x4 sb[4], fa[6];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sb[s] = *(const u32x4*)(xsb + s * 1024 + lane16);
+      fa[0] = frag(img, REC_AQK, 0); fa[1] = frag(img, REC_AQK, 2); fa[2] = frag(img, REC_AQK, 4);
+      fa[3] = frag(img, REC_AQK, 5); fa[4] = frag(img, REC_AQK, 6); fa[5] = frag(img, REC_AQK, 7);
+      // (q_hat S)^T: lane (g, j) register r <-> column v0 + 4g + r, time 16m + j
+      f32x4 accO[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) accO[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          accO[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(sb[s]), mf(fq[4 * m + s]), accO[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) accO[m] *= egv[m];
+      lds_barrier();                     // M(ci): v_new(ci) published, H1(ci+1) landed
+      u32x4 vn[2];
+      vn[0] = *(const u32x4*)(xvn + lane16);
+      vn[1] = *(const u32x4*)(xvn + 1024 + lane16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fq[i] = frag(img_next, REC_QH, i);        // next chunk (stale but harmless after the last one)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(img_next + REC_EG + (16 * m + j) * 4);
+      // + v_new^T Aqk^T (the blocks (m < 2, s2 = 1) lie strictly above the diagonal)
+      accO[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[0]), accO[0], 0, 0, 0);
+      accO[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[1]), accO[1], 0, 0, 0);
+      accO[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[2]), accO[2], 0, 0, 0);
+      accO[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[4]), accO[3], 0, 0, 0);
+      accO[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[1]), mf(fa[3]), accO[2], 0, 0, 0);
+      accO[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[1]), mf(fa[5]), accO[3], 0, 0, 0);
+      if (tc0 + GC <= T) {               // full chunk (wave-uniform): four unconditional 8-byte row stores
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          *(u32x2*)(orow + m * ostep) = u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (tc0 + 16 * m + j < T)
+            *(u32x2*)(orow + m * ostep) = u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
+      }
+      orow += 4 * ostep;
+    }
+    return;
+  }
+
+  // =========================== state wave ===========================
   // state slab: tile t = rows 16t..16t+15, lane (g, j) register r <-> S[16t + 4g + r][v0 + j]
   f32x4 S[8];
   {
@@ -520,115 +703,67 @@ __global__ __launch_bounds__(64 * NW) void gdn_chunk_scan_kernel(
         for (int r = 0; r < 4; ++r) S[t][r] = bf2f(raw[4 * t + r]);
     }
   }
+  // Wn fragments, u and e^gamma_L of the NEXT chunk are loop-carried: requested a phase ahead of their use
+  u32x4 fw[16];
+  u32x2 uu[4];
+  float egl;
+  auto load_h1_frags = [&](const unsigned char* im) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fw[i] = frag(im, REC_WN, i);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(im + IMG_U + pair * 2048 + m * 512 + lane * 8);
+    egl = *(const float*)(im + REC_EGL);
+  };
+  lds_barrier();                         // P: H1(0) has landed
+  load_h1_frags(smem);
 
   for (int ci = 0; ci < nt_seg; ++ci) {
-    const unsigned char* img = smem + (ci & 1) * IMG;
-    const int tc0 = t_seg0 + ci * GC;
-    IVL_T(tc_a);
-    // This wave's pieces of chunk ci have landed: everything but the 4 output stores of the previous chunk, which
-    // were issued after them (vmcnt retires in issue order).
-    if (ci == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    lds_barrier();                       // ... and so have everyone else's; every wave has left chunk ci - 1
-    IVL_T(tc_b);
-    if (ci + 1 < nt_seg) issue(ci + 1);  // overwrites the image of chunk ci - 1
-    IVL_T(tc_c);
-
-    auto blk = [&](int off, int idx) { return mf(*(const u32x4*)(img + off + idx * 1024 + lane16)); };
-
-    // ---- B-operand fragments: the state (bf16) ----------------------------------------------------------------
+    const unsigned char* img = smem + (ci & 1) * IMG_BYTES;
+    const unsigned char* img_next = smem + ((ci + 1) & 1) * IMG_BYTES;
+    IVL_T(tc_0);
+    // ---- B-operand fragments: the state (bf16); published for the output wave --------------------------------------
     u32x4 sb[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
       sb[s] = pack8(S[2 * s][0], S[2 * s][1], S[2 * s][2], S[2 * s][3], S[2 * s + 1][0], S[2 * s + 1][1], S[2 * s + 1][2], S[2 * s + 1][3]);
-    // ---- bf16(beta v): LDS transpose read of the raw slab [time][16 cols]: lane (g, j) <- times 32 s2 + {4g.., 16+4g..}
-    u32x4 vb[2];
-    {
-      const unsigned char* vimg = img + IMG_V + wave * 2048;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int time0 = 32 * s2 + 4 * g;
-        const unsigned char* p = vimg + (time0 + (j >> 2)) * 32 + 8 * (j & 3);
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * 32));
-        const f32x4 b0 = *(const f32x4*)(img + REC_BETA + time0 * 4), b1 = *(const f32x4*)(img + REC_BETA + (time0 + 16) * 4);
-        u32x2 w0, w1;
-        __builtin_memcpy(&w0, &a0, 8);
-        __builtin_memcpy(&w1, &a1, 8);
-        vb[s2] = pack8(bflo(w0.x) * b0[0], bfhi(w0.x) * b0[1], bflo(w0.y) * b0[2], bfhi(w0.y) * b0[3],
-                       bflo(w1.x) * b1[0], bfhi(w1.x) * b1[1], bflo(w1.y) * b1[2], bfhi(w1.y) * b1[3]);
-      }
+      *(u32x4*)(xsb + s * 1024 + lane16) = sb[s];
     }
-    // ---- u = Tu (beta v);  v_new = u + Wn S   (time tiles m, lane (g, j) register r <-> time 16m + 4g + r, column j) ---
+    IVL_T(tc_a);
+    lds_barrier();                       // T(ci): H2 of this chunk has landed
+    IVL_T(tc_b);
+    u32x4 fk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fk[i] = frag(img, REC_KDT, i);              // land under the 16 MFMAs below
+    // ---- v_new = u + Wn S   (time tiles m, lane (g, j) register r <-> time 16m + 4g + r, column j); u (bf16) is the C input
     f32x4 accV[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) accV[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if (m < 2 && s2 == 1) continue;                 // strictly upper blocks of Tu
-        accV[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blk(REC_TU, 2 * m + s2), mf(vb[s2]), accV[m], 0, 0, 0);
-      }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)                         // the reference keeps u in bf16 (wy_fast.py:341-343): same rounding point
-#pragma unroll
-      for (int r = 0; r < 4; ++r) accV[m][r] = bf_round(accV[m][r]);
+    for (int m = 0; m < 4; ++m) accV[m] = f32x4{bflo(uu[m].x), bfhi(uu[m].x), bflo(uu[m].y), bfhi(uu[m].y)};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        accV[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blk(REC_WN, 4 * m + s), mf(sb[s]), accV[m], 0, 0, 0);
-    // ---- (q_hat S)^T, independent of v_new: fills the MFMA pipe while v_new is converted ------------------------
-    f32x4 accO[4];
+        accV[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(fw[4 * m + s]), mf(sb[s]), accV[m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) accO[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        accO[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(sb[s]), blk(REC_QH, 4 * m + s), accO[m], 0, 0, 0);
+    for (int t = 0; t < 8; ++t) S[t] *= egl;
     u32x4 vn[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
       vn[s2] = pack8(accV[2 * s2][0], accV[2 * s2][1], accV[2 * s2][2], accV[2 * s2][3],
                      accV[2 * s2 + 1][0], accV[2 * s2 + 1][1], accV[2 * s2 + 1][2], accV[2 * s2 + 1][3]);
-    // ---- S = e^{gamma_L} S + Kd^T v_new ----------------------------------------------------------------------------
-    {
-      const float egl = *(const float*)(img + REC_EGL);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) S[t] *= egl;
+      *(u32x4*)(xvn + s2 * 1024 + lane16) = vn[s2];
     }
+    IVL_T(tc_c);
+    lds_barrier();                       // M(ci): H1 of the next chunk has landed; every wave is done with H1 of this one
+    IVL_T(tc_d);
+    load_h1_frags(img_next);             // chunk ci + 1 (stale but harmless data after the last chunk)
+    // ---- S = e^{gamma_L} S + Kd^T v_new ----------------------------------------------------------------------------
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blk(REC_KDT, 2 * t + s2), mf(vn[s2]), S[t], 0, 0, 0);
-    // ---- o^T = scale ((q_hat S)^T e^gamma + v_new^T Aqk^T): lane (g, j) register r <-> column v0 + 4g + r, time 16m + j --
-#pragma unroll
-    for (int m = 0; m < 4; ++m) accO[m] *= *(const float*)(img + REC_EG + (16 * m + j) * 4);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if (m < 2 && s2 == 1) continue;                 // strictly upper blocks of Aqk
-        accO[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[s2]), blk(REC_AQK, 2 * m + s2), accO[m], 0, 0, 0);
-      }
-    bf16_t* orow = o + (((size_t)b * T + tc0 + j) * H + h) * GV + v0 + 4 * g;
-    if (tc0 + GC <= T) {                                // full chunk: exactly 4 stores (counted by the vmcnt(4) above)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        *(u32x2*)(orow + (size_t)16 * m * H * GV) =
-            u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
-    } else {                                            // zero-padded tail chunk (always the last one)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (tc0 + 16 * m + j < T)
-          *(u32x2*)(orow + (size_t)16 * m * H * GV) =
-              u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
-    }
-    IVL_T(tc_d);
-    IVL_TACC(t_wait, tc_b, tc_a); IVL_TACC(t_issue, tc_c, tc_b); IVL_TACC(t_comp, tc_d, tc_c);
+        S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(fk[2 * t + s2]), mf(vn[s2]), S[t], 0, 0, 0);
+    IVL_T(tc_e);
+    IVL_TACC(t_bar, tc_b, tc_a); IVL_TACC(t_bar2, tc_d, tc_c); IVL_TACC(t_h1, tc_c, tc_b); IVL_TACC(t_h2, tc_e, tc_d); IVL_TACC(t_sb, tc_a, tc_0);
   }
   IVL_T(ts1);
 
@@ -649,12 +784,12 @@ __global__ __launch_bounds__(64 * NW) void gdn_chunk_scan_kernel(
     }
   }
   IVL_T(ts2);
-  IVL_TOUT(16, ts0); IVL_TOUT(17, t_wait); IVL_TOUT(18, t_issue); IVL_TOUT(19, t_comp); IVL_TOUT(20, ts1 - ts0); IVL_TOUT(21, ts2 - ts1);
-  IVL_TOUT(22, ts2);
+  IVL_TOUT(16, ts0); IVL_TOUT(17, t_bar); IVL_TOUT(18, t_h1); IVL_TOUT(19, t_h2); IVL_TOUT(20, ts1 - ts0); IVL_TOUT(21, ts2 - ts1);
+  IVL_TOUT(22, ts2); IVL_TOUT(23, t_bar2); IVL_TOUT(24, t_sb);
 }
 
 #ifdef IVL_TRACE
-int g_scan_nw = 4;                         // developer knob (trace build only): waves per scan workgroup, 2 or 4
+int g_scan_ncw = 0;                        // developer knob (trace build only): force 2 or 4 compute waves per scan workgroup
 #endif
 
 }  // namespace ivl
@@ -670,8 +805,8 @@ static void gdn_chunk_init_device() {
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 63], [] {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_BYTES);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * img_bytes(4));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * img_bytes(2));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_lds_bytes(4));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_lds_bytes(2));
   });
 }
 
@@ -702,27 +837,28 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
   const int segc = seg_chunks(NT);
   unsigned char* wsb = (unsigned char*)workspace;
   float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * REC_STRIDE) : nullptr;
-  int nw = 4;
+  int ncw = B * H * 4 <= 128 ? 2 : 4;          // 32-column workgroups while 64-column ones would leave half the CUs idle
 #ifdef IVL_TRACE
-  nw = g_scan_nw;
+  if (g_scan_ncw) ncw = g_scan_ncw;
 #endif
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
     const bool first = c0 == 0, last = c0 + nseg >= NT;
     hipLaunchKernelGGL(gdn_chunk_prepare_kernel, dim3(nseg, B * H), dim3(512), P_BYTES, st,
-                       (const bf16_t*)q, (const bf16_t*)k, g, (const bf16_t*)beta, wsb, T, H, c0 * GC, nseg, use_qk_l2norm);
+                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb, T, H, c0 * GC, nseg,
+                       use_qk_l2norm);
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
     if (rc != IVL_OK) return rc;
     const void* hin = first ? h0 : (const void*)carry;
     const int hin_dt = first ? h0_dtype : IVL_F32;
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
-    if (nw == 2)
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2>), dim3(B * H, 8), dim3(128), 2 * img_bytes(2), st, (const unsigned char*)wsb,
-                         (const bf16_t*)v, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
+    if (ncw == 2)
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2>), dim3(B * H, 8), dim3(384), scan_lds_bytes(2), st, (const unsigned char*)wsb,
+                         (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     else
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4>), dim3(B * H, 4), dim3(256), 2 * img_bytes(4), st, (const unsigned char*)wsb,
-                         (const bf16_t*)v, (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4>), dim3(B * H, 4), dim3(640), scan_lds_bytes(4), st, (const unsigned char*)wsb,
+                         (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
   }

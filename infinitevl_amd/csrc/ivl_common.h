@@ -69,7 +69,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 #define IVL_TRACE_DECL(unit)                                                                      \
   static __device__ long long* ivl_trace_buf = nullptr;                                            \
   void trace_set_##unit(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ivl_trace_buf), &p, sizeof(p)); }
-#define IVL_T(name) const long long name = (long long)__builtin_readcyclecounter()
+#define IVL_T(name)                                    \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  const long long name = (long long)__builtin_readcyclecounter(); \
+  __builtin_amdgcn_sched_barrier(0)
 #define IVL_TVAR(name) long long name = 0
 #define IVL_TACC(acc, t1, t0) acc += (t1) - (t0)
 #define IVL_TOUT(slot, value)                                                                      \

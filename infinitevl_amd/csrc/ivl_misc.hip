@@ -265,15 +265,15 @@ using namespace ivl;
 extern "C" int ivl_abi_version(void) { return IVL_ABI_VERSION; }
 #ifdef IVL_TRACE
 // Developer build only (libivl_hip_trace.so, never shipped): device buffer of >= 64 int64 slots that the instrumented
-// kernels stamp with the shader clock at phase boundaries (NULL switches the timeline off), and the scan-geometry knob.
+// kernels fill with phase durations (NULL switches the timeline off).
 namespace ivl {
 void trace_set_gdn(void* p);
-extern int g_scan_nw;
+extern int g_scan_ncw;
 }
 extern "C" IVL_API void ivl_debug_set_trace(void* device_buffer) {
   ivl::trace_set_gdn(device_buffer);
 }
-extern "C" IVL_API void ivl_debug_set_scan_waves(int nw) { ivl::g_scan_nw = nw == 2 ? 2 : 4; }
+extern "C" IVL_API void ivl_debug_set_scan_waves(int ncw) { ivl::g_scan_ncw = ncw; }
 #endif
 extern "C" const char* ivl_last_error(void) { return g_err; }
 

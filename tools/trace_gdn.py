@@ -6,10 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from infinitevl_amd import _lib, ops
-lib = _lib.load(os.path.join(ROOT, "infinitevl_amd", "libivl_hip_trace.so"))
+lib = _lib.load(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "infinitevl_amd", "libivl_hip_trace.so"))
 dev = torch.device("cuda", 0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-lib.ivl_debug_set_scan_waves(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+lib.ivl_debug_set_scan_waves(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 B, H, K, V = 1, 16, 128, 256
 g_ = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g_).to(torch.bfloat16)
@@ -33,6 +33,6 @@ for it in range(3):
     t = trace.cpu().tolist()
     print(f"--- iter {it}: prepare (cycles): load+l2norm {t[1]} | L,A mfma {t[2]} | solve L0 {t[3]} L1 {t[4]} L2 {t[5]} | Tu,w {t[6]} "
           f"| total {t[7]-t[0]}")
-    print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: wait+barrier {t[17]//NT} issue {t[18]//NT} compute {t[19]//NT}) "
+    print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]}")
 lib.ivl_debug_set_trace(None)
