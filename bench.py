@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): prefill tok/s + decode tok/s, InfiniteVL-3B @128K sequence.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,8 +11,8 @@ the shipped config.json -- no checkpoint offline), streaming prefill in 256-toke
 sliding window overridden to 4096, one hipGraph replay per step, one sequence per GPU (batch-sharded
 replicas; the only collective is the final logits all-gather).  A "step" = one 256-token chunk through
 all 36 layers (27 Gated DeltaNet + 9 SWA mixers on the gfx950 kernels of this repo, the projections/MLP
-on stock rocBLAS/hipBLASLt).  Untimed setup fills the SWA window (17 steps) so that every warm-up and
-timed step is a steady-state full-window step; K=512 timed steps = 131072 tokens (the default).
+on stock rocBLAS/hipBLASLt).  Untimed setup streams 131072 - K*256 tokens (at least the 17 steps that fill the SWA window), so that the K
+timed steps are steady-state full-window steps that END at exactly 128K tokens of context whatever K is.
 After the timed prefill region a decode leg (graph-captured greedy single-token steps at that context)
 is timed separately and reported as `decode_tok_s`.
 
@@ -59,10 +60,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=256, help="tokens per streaming step")
     ap.add_argument("--window", type=int, default=4096)
+    ap.add_argument("--context", type=int, default=131072, help="context length at the END of the timed region")
     ap.add_argument("--decode-steps", type=int, default=128)
     ap.add_argument("--layers", type=int, default=36, help="debug only; the reported config is 36")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,11 +132,12 @@ def kernel_timings(device, chunk, window, only=None):
         return q, k, v, g, beta
 
     state = torch.randn(B, H, K, V, device=device, generator=g_).to(torch.bfloat16)
-    # GDN bytes: 24,672 B/token/layer + fp32 state read+write per call
+    # GDN bytes: 24,672 B/token/layer + state read+write per call in the dtype actually passed (bf16 cache: SURVEY.md Q5)
+    sbytes = 2 * H * K * V * state.element_size()
     q, k, v, g, beta = gdn_inputs(T)
     add("gdn_chunk(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
         q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        20, 27, "hbm", 24672.0 * T + 2 * H * K * V * 4)
+        20, 27, "hbm", 24672.0 * T + sbytes)
     # SWA prefill: T queries over a full ring (W-1 cached keys) + T new keys; 8192*min(p+1,W) FLOP/token/layer
     kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
     pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
@@ -162,12 +165,12 @@ def kernel_timings(device, chunk, window, only=None):
     q1, k1, v1, g1, b1 = gdn_inputs(1)
     add("gdn_recurrent(decode)", lambda: ops.fused_recurrent_gated_delta_rule(
         q1, k1, v1, g1, b1, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        100, 27, "hbm", 24672.0 + 2 * H * K * V * 2)
+        100, 27, "hbm", 24672.0 + sbytes)
     proj1 = rn(B, 1, ld)
     cols6 = (cols[0], cols[1], cols[2], Dq + Dk + Dv, cols[3], cols[4])
     add("gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)", lambda: ops.gdn_decode_step(
         proj1, cols6, cw, cs, A32, dt32, wn, 1e-5, state, H, K, V, K ** -0.5), 100, 0, "hbm",
-        2.0 * ld + 2 * H * K * V * 2 + 2.0 * H * V)
+        2.0 * ld + sbytes + 2.0 * H * V)
     qd, kd1, vd1 = rn(B, 1, Hq, d), rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
     add("swa_decode", lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
                                               pos_dev=pos_dev), 100, 9, "hbm", 1024.0 * window)
@@ -190,7 +193,7 @@ def kernel_timings(device, chunk, window, only=None):
     stateb = torch.randn(Bb, H, K, V, device=device, generator=g_).to(torch.bfloat16)
     add("gdn_chunk@B=8", lambda: ops.chunk_gated_delta_rule(
         qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb),
-        10, 0, "hbm", Bb * (24672.0 * T + 2 * H * K * V * 4))
+        10, 0, "hbm", Bb * (24672.0 * T + sbytes))
     kcb, vcb = rn(Bb, Hkv, C, d), rn(Bb, Hkv, C, d)
     qsb, knb, vnb = rn(Bb, T, Hq, d), rn(Bb, T, Hkv, d), rn(Bb, T, Hkv, d)
     add("swa_prefill@B=8", lambda: ops.swa_forward(qsb, knb, vnb, window=window, scaling=d ** -0.5, k_cache=kcb,
@@ -202,7 +205,7 @@ def kernel_timings(device, chunk, window, only=None):
     qL, kL, vL, gL, bL = gdn_inputs(TL)
     add("gdn_chunk@T=4096", lambda: ops.chunk_gated_delta_rule(
         qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        5, 0, "hbm", 24672.0 * TL + 2 * H * K * V * 4)
+        5, 0, "hbm", 24672.0 * TL + sbytes)
     qsL, knL, vnL = rn(B, TL, Hq, d), rn(B, TL, Hkv, d), rn(B, TL, Hkv, d)
     add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),
         5, 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
@@ -222,7 +225,7 @@ def pmc_traffic(kernel_name, chunk, window):
         return None
     k = json.load(open(files[-1]))["kernels"]
     want = {
-        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel", 16384), ("ivl::gdn_chunk_scan_kernel", 32768)],
+        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel", 32768), ("ivl::gdn_chunk_scan_kernel<2>", 49152)],
         "swa_prefill": [("ivl::swa_fwd_kernel<false,", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
         "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 36864)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
@@ -273,20 +276,43 @@ def cpu_baseline(chunk, window):
         if el > 12.0 or n >= 40:
             break
     per_period = el / n
-    return dict(value=chunk / (per_period * 9.0), unit="tok/s", cores=torch.get_num_threads(), kind="port",
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=chunk / (per_period * 9.0), unit="tok/s", cores=torch.get_num_threads(), cpu_model=cpu_model,
+                host_logical_cpus=ncores, kind="port",
                 sample=f"oracle/model.py on host CPU: one 4-layer period (1 SWA + 3 GDN decoder layers, fp32, real "
                        f"InfiniteVL-3B shapes) x {n} steps of {chunk} tokens with a full {window}-key window, "
                        f"{per_period:.3f} s per period-step, extrapolated x9 to 36 layers")
 
 
+def _self_spawn(n: int) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-execute under torch.distributed.run,
+    one rank per GPU of this node (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_spawn(args.gpus)
     from infinitevl_amd import dist as ivd
     # IVL_DIST_BACKEND=gloo lets the N > 1 control flow be exercised with several ranks on ONE GPU (RCCL refuses two
     # ranks per device); production is always "nccl" (= RCCL over xGMI)
     rank, world, local_rank = ivd.init_distributed(os.environ.get("IVL_DIST_BACKEND", "nccl"))
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import infinitevl_amd
@@ -310,8 +336,10 @@ def main():
 
     step = GraphedStep(model, cache, B_local, T, logits_to_keep=1)
     step.capture()
-    # untimed setup: fill the sliding window so every later step is a steady-state step
-    fill = (args.window - 1 + T - 1) // T + 1
+    # untimed setup: stream up to (context - steps*T) tokens, at least the window fill, so that every timed step is a
+    # steady-state full-window step and the timed region ENDS at `context` tokens (128K) whatever --steps is
+    fill_min = (args.window - 1 + T - 1) // T + 1
+    fill = max(fill_min, (args.context - args.steps * T) // T - args.warmup)
     for i in range(fill):
         step.step(frames[i % 4])
     for i in range(args.warmup):
@@ -407,7 +435,7 @@ def main():
                             f"at the reached context",
                 "global_batch": B_local * world, "seq_len": ctx_tokens, "tokens_timed": tokens_global,
                 "parallelism": f"dp{world} (batch-sharded replicas, one logits all-gather)",
-                "decode_steps": args.decode_steps, "window_fill_steps_untimed": fill,
+                "decode_steps": args.decode_steps, "untimed_steps_before_timed_region": fill + args.warmup,
             },
             "logits_finite": finite, "peak_mem_gib": round(mem_gb, 2),
         }

@@ -162,10 +162,15 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         return int(self.sliding_window)
 
     def crop(self, max_length: int) -> None:
+        """std:192-213: keeps the LAST new_size cached tokens, moved to the front, and restarts the counters at
+        new_size.  Only allowed while the window is not full, where ring slot == absolute position."""
         if self.get_seq_length() >= self.sliding_window:                    # std:192-194
             raise ValueError("Cropping is forbidden after filling SWA window (to avoid state loss)")
         new_size = max(0, self.size - abs(max_length)) if max_length < 0 else min(self.size, max_length)
-        # window not yet full => ring slot == absolute position: keeping the first new_size tokens is a counter reset
+        if self.capacity > 0 and 0 < new_size < self.size:
+            lo = self.size - new_size
+            self._buf_keys[:, :, :new_size, :].copy_(self._buf_keys[:, :, lo:self.size, :].clone())
+            self._buf_values[:, :, :new_size, :].copy_(self._buf_values[:, :, lo:self.size, :].clone())
         self.size = int(new_size)
         self.cumulative_length = int(new_size)
         self._pos_dev.fill_(int(new_size))
@@ -332,8 +337,14 @@ class StaticLinearLayerPrealloc(_HFLayer):
         return
 
     def reset(self) -> None:
+        """Back to the state of a fresh cache.  The tensors are zeroed as well: an eager first call ignores them
+        (std:298-300), but a captured hipGraph always reads them, and must then see the same zero history."""
         self.seq_len = 0
         self.start = False
+        for n in ("conv_state_q", "conv_state_k", "conv_state_v", "recurrent_state"):
+            t = getattr(self, n)
+            if t is not None:
+                t.zero_()
 
     # ---- state hand-off (sequence-parallel prefill, SURVEY.md 8f-4) ------------------------------------
     def carried_tensors(self):

@@ -514,6 +514,10 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   IVL_REQUIRE(a->cache_capacity >= 0 && (a->cache_capacity == 0 || (a->k_cache && a->v_cache)), IVL_ERR_INVALID_ARG,
               "ivl_swa_fwd: cache_capacity=%d needs k_cache/v_cache", a->cache_capacity);
   IVL_REQUIRE(a->pos_dev != nullptr || a->pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: negative pos");
+  // new-key rows are addressed with 32-bit element offsets from the (batch, kv-head) base
+  IVL_REQUIRE((long long)a->T_new * a->kn_st < (1LL << 32) && a->kn_st >= 0, IVL_ERR_UNSUPPORTED,
+              "ivl_swa_fwd: T_new * kn_st = %lld elements exceeds the 32-bit row addressing of the kernel (split the call)",
+              (long long)a->T_new * a->kn_st);
   const int G = a->Hq / a->Hkv;
   const bool pack = (long long)a->T * G <= SWA_QT && G <= 16;
   // worst-case number of key tiles a workgroup walks (n_prev unknown under graph replay -> capacity)

@@ -22,7 +22,6 @@ from .cache import StaticCachePrealloc
 
 import os as _os
 
-_XLAYER_FUSE = _os.environ.get("IVL_NO_XLAYER_FUSE") != "1"     # A/B knob for the cross-layer add+norm fusion
 from .modules import GatedDeltaNet, InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
 
 
@@ -222,10 +221,7 @@ class InfiniteVLTextStack(nn.Module):
         # (one add+norm launch instead of add, norm): `resid` is the residual stream, `pend` the not-yet-added
         # MLP output of the previous layer.
         resid, pend = inputs_embeds, None
-        _xl = _XLAYER_FUSE
         for layer in self.layers:                                                    # std:1555-1571
-            if not _xl and pend is not None:
-                resid, pend = resid + pend, None
             if pend is None:
                 y = layer.input_layernorm(resid)
             else:
@@ -346,9 +342,17 @@ class GraphedStep:
         self.cache.copy_from(saved)
         self.position_ids.copy_(saved_pos)
 
+    def reset(self) -> None:
+        """Start a new sequence on the same graph: cache counters and state tensors back to empty, positions to 0."""
+        self.cache.reset()
+        self.cache.ensure_started()
+        self.position_ids.copy_(torch.arange(self.T, device=self.position_ids.device)[None, None, :]
+                                .expand(3, self.B, self.T))
+
     def step(self, inputs_embeds: Optional[torch.Tensor] = None):
         if self.graph is None:
             self.capture()
+        self.cache.ensure_started()          # a replayed graph always reads the cache tensors (no-op once started)
         if inputs_embeds is not None:
             self.inputs_embeds.copy_(inputs_embeds)
         self.graph.replay()
@@ -397,6 +401,7 @@ class GraphedDecode:
         """One decode step; the new token is left in self.token (device)."""
         if self.graph is None:
             self.capture()
+        self.cache.ensure_started()
         self.graph.replay()
         self.cache.advance(1)
         return self.token

@@ -164,6 +164,10 @@ class GatedDeltaNet(nn.Module):
             raise UserWarning("ShortConvolution is crucial to the performance. Do not turn it off.")
         if not self.use_gate:
             raise NotImplementedError("InfiniteVL ships use_gate=True (configuration_infinitevl.py)")
+        if self.num_key_value_heads != self.num_heads:
+            raise NotImplementedError(
+                f"num_linear_key_value_heads ({self.num_key_value_heads}) != num_linear_heads ({self.num_heads}): the "
+                f"kernels index q, k and v with one head count (InfiniteVL ships 16 / 16)")
 
         self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
         self.k_proj = nn.Linear(self.hidden_size, self.key_dim, bias=False)

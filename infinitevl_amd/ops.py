@@ -41,22 +41,33 @@ def _need_gpu(*ts: torch.Tensor) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
-# workspace: one growable scratch buffer per device, reused by every call on the current stream
+# workspace: one growable scratch buffer per (device, stream, tag)
 # ---------------------------------------------------------------------------------------------
-_WORKSPACES: Dict[Tuple[int, str], torch.Tensor] = {}
+_WORKSPACES: Dict[Tuple[int, int, str], torch.Tensor] = {}
+_GRAPH_PINNED: Dict[Tuple[int, int, str], bool] = {}
+_RETIRED: list = []          # buffers a captured hipGraph may still address: never returned to the allocator
 
 
 def get_workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch.Tensor:
-    """Caller-owned scratch handed to the C ABI (the library never allocates).  Kernels that use it
-    are ordered by the stream, so one buffer per (device, tag) suffices; it only ever grows.  Growth
-    while a stream is being captured into a hipGraph is refused -- run one warm-up step first."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Caller-owned scratch handed to the C ABI (the library never allocates).  One buffer per (device, stream,
+    tag): kernels that use it are ordered by that stream.  It only ever grows -- and a buffer that was handed out
+    while its stream was being captured is baked into a hipGraph, so when a later eager call outgrows it the old
+    buffer is RETIRED (kept alive for the life of the process), never freed: replaying the graph stays valid.
+    Growth during capture itself is refused -- run one warm-up step first."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, int(torch.cuda.current_stream(device).cuda_stream), tag)
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError("workspace would have to grow during hipGraph capture; run a warm-up step first")
+        if ws is not None and _GRAPH_PINNED.get(key):
+            _RETIRED.append(ws)
+            _GRAPH_PINNED[key] = False
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WORKSPACES[key] = ws
+    if capturing:
+        _GRAPH_PINNED[key] = True
     return ws
 
 
@@ -77,6 +88,9 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
         raise NotImplementedError("variable-length (cu_seqlens) inputs are not used by InfiniteVL (std:1223)")
     B, T, H, K = k.shape
     V = v.shape[-1]
+    if not (q.shape[2] == k.shape[2] == v.shape[2] == g.shape[2] == beta.shape[2]):
+        raise ValueError(f"q, k, v, g, beta must share the head count (got {q.shape[2]}, {k.shape[2]}, {v.shape[2]}, "
+                         f"{g.shape[2]}, {beta.shape[2]}): grouped key/value heads are not supported by the kernels")
     if scale is None:
         scale = K ** -0.5                                                                 # chunk.py:373-374
     else:

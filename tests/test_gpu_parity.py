@@ -131,6 +131,16 @@ def test_gdn_head_first_layout_equals_time_major():
         assert o_hf.shape == (2, 3, 70, 256) and torch.equal(o_hf.transpose(1, 2), o_tm) and torch.equal(s_hf, s_tm)
 
 
+def test_gdn_head_count_mismatch_raises():
+    from infinitevl_amd import ops
+    q = bf(torch.randn(1, 8, 4, 128)).to(DEV)
+    k = bf(torch.randn(1, 8, 2, 128)).to(DEV)
+    v = bf(torch.randn(1, 8, 2, 256)).to(DEV)
+    g = torch.zeros(1, 8, 2, device=DEV)
+    with pytest.raises(ValueError):
+        ops.chunk_gated_delta_rule(q, k, v, g, bf(g), use_qk_l2norm_in_kernel=True)
+
+
 def test_gdn_error_behaviour():
     from infinitevl_amd import ops
     z = torch.zeros(2, 4, 2, 128, dtype=torch.bfloat16, device=DEV)
@@ -483,6 +493,68 @@ def test_hipgraph_from_a_fresh_poisoned_cache_equals_eager_first_call():
             h2, _ = gs.step(x)
             assert torch.isfinite(h1.float()).all() and torch.equal(h1, h2)
             pos += T
+
+
+def test_graph_survives_a_larger_eager_call_and_a_reset():
+    """(a) the scratch buffer baked into a captured graph must stay alive when a later eager call outgrows
+    it (retired, not freed); (b) reset() + replay of an existing graph equals a fresh eager sequence."""
+    from infinitevl_amd import ops
+    from infinitevl_amd.harness import GraphedStep
+    stack, hc, _, _ = _small_stack(window=96)
+    T = 70
+    xs = [bf(torch.randn(1, T, hc.hidden_size) * 0.5).to(DEV) for _ in range(4)]
+    with torch.no_grad():
+        c1, c2 = stack.allocate_inference_cache(1), stack.allocate_inference_cache(1)
+        gs = GraphedStep(stack, c2, 1, T)
+        gs.capture()
+        ws_before = {k: v.data_ptr() for k, v in ops._WORKSPACES.items()}
+        # an eager call far larger than the frame: both the GDN records and the SWA partials outgrow their buffers
+        big = bf(torch.randn(1, 4200, hc.hidden_size) * 0.5).to(DEV)
+        cbig = stack.allocate_inference_cache(1)
+        stack(inputs_embeds=big, position_ids=torch.arange(4200, device=DEV)[None, None, :].expand(3, 1, 4200),
+              past_key_values=cbig)
+        grown = [k for k, v in ops._WORKSPACES.items() if k in ws_before and v.data_ptr() != ws_before[k]]
+        assert grown, "the big call was meant to outgrow a captured workspace"
+        assert len(ops._RETIRED) >= len(grown)
+        junk = [torch.full((1 << 22,), 7, dtype=torch.uint8, device=DEV) for _ in range(8)]     # would land on freed memory
+        pos = 0
+        for x in xs[:2]:
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :].expand(3, 1, T)
+            h1 = stack(inputs_embeds=x, position_ids=pid, past_key_values=c1)[0]
+            h2, _ = gs.step(x)
+            assert torch.equal(h1, h2)
+            pos += T
+        del junk
+        # (b) new sequence on the same graph
+        gs.reset()
+        c3 = stack.allocate_inference_cache(1)
+        pos = 0
+        for x in xs[2:]:
+            pid = torch.arange(pos, pos + T, device=DEV)[None, None, :].expand(3, 1, T)
+            h1 = stack(inputs_embeds=x, position_ids=pid, past_key_values=c3)[0]
+            h2, _ = gs.step(x)
+            assert torch.equal(h1, h2)
+            pos += T
+        assert c2.get_seq_length() == 2 * T
+
+
+def test_swa_crop_keeps_the_last_tokens_like_the_reference():
+    """std:192-213: crop keeps the LAST new_size tokens at the front and restarts the counters."""
+    from infinitevl_amd.cache import StaticSlidingWindowLayerPrealloc
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    cfg = InfiniteVLTextConfig(sliding_window=64, num_hidden_layers=4)
+    layer = StaticSlidingWindowLayerPrealloc(config=cfg, batch_size=1, device=DEV, dtype=torch.bfloat16)
+    k = bf(torch.randn(1, 2, 20, 128)).to(DEV)
+    v = bf(torch.randn(1, 2, 20, 128)).to(DEV)
+    layer.update(k, v)
+    layer.crop(7)
+    assert layer.size == 7 and layer.cumulative_length == 7 and int(layer._pos_dev.item()) == 7
+    assert torch.equal(layer.keys, k[:, :, 13:20]) and torch.equal(layer.values, v[:, :, 13:20])
+    layer.crop(-3)
+    assert layer.size == 4 and torch.equal(layer.keys, k[:, :, 16:20])
+    layer.update(bf(torch.randn(1, 2, 70, 128)).to(DEV), bf(torch.randn(1, 2, 70, 128)).to(DEV))
+    with pytest.raises(ValueError):
+        layer.crop(3)
 
 
 def test_clone_branch_decode_then_resume_stream():

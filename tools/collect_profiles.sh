@@ -15,6 +15,24 @@ rm -rf /tmp/prof_bench /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- \
     python $REPO/bench.py --steps 64 --warmup 4 --decode-steps 32 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp /tmp/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
+# the same trace keyed by (kernel, grid): one row per launch SHAPE, so the 256-token step's launches are not mixed with the
+# decode / 4096-token / batched shapes of the same kernel name (avg_ns of gdn_chunk_prepare@32768 + gdn_chunk_scan<2>@49152
+# is the prefill step's gdn_chunk launch; bench.py's HIP-event `avg_launch_ms` must agree with it)
+python - <<PY
+import csv, collections, glob
+rows = []
+for f in glob.glob("/tmp/prof_bench/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+agg = collections.defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    agg[(name, int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open("$OUT/${TAG}_bench_kernel_by_grid.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "grid_threads", "workgroup_threads", "launches", "avg_ns", "min_ns", "max_ns", "total_ns"])
+    for (name, grid, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([name, grid, wg, len(v), round(sum(v) / len(v), 1), min(v), max(v), sum(v)])
+PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $REPO/tools/kernel_bench.py --only '!large' > /dev/null 2>&1
 done
