@@ -41,21 +41,22 @@ def _need_gpu(*ts: torch.Tensor) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
-# workspace: one growable scratch buffer per (device, stream, tag)
+# workspace: one growable scratch buffer per (device, tag)
 # ---------------------------------------------------------------------------------------------
-_WORKSPACES: Dict[Tuple[int, int, str], torch.Tensor] = {}
-_GRAPH_PINNED: Dict[Tuple[int, int, str], bool] = {}
+_WORKSPACES: Dict[Tuple[int, str], torch.Tensor] = {}
+_GRAPH_PINNED: Dict[Tuple[int, str], bool] = {}
 _RETIRED: list = []          # buffers a captured hipGraph may still address: never returned to the allocator
 
 
 def get_workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch.Tensor:
-    """Caller-owned scratch handed to the C ABI (the library never allocates).  One buffer per (device, stream,
-    tag): kernels that use it are ordered by that stream.  It only ever grows -- and a buffer that was handed out
-    while its stream was being captured is baked into a hipGraph, so when a later eager call outgrows it the old
-    buffer is RETIRED (kept alive for the life of the process), never freed: replaying the graph stays valid.
-    Growth during capture itself is refused -- run one warm-up step first."""
+    """Caller-owned scratch handed to the C ABI (the library never allocates).  One buffer per (device, tag), used by
+    one stream at a time (the package issues everything on the current stream; a hipGraph capture re-uses the buffer of
+    its warm-up, ordered by the capture's own stream joins -- callers that overlap several streams pass distinct tags).
+    It only ever grows -- and a buffer that was handed out while a stream was being captured is baked into a hipGraph,
+    so when a later eager call outgrows it the old buffer is RETIRED (kept alive for the life of the process), never
+    freed: replaying the graph stays valid.  Growth during capture itself is refused -- run one warm-up step first."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, int(torch.cuda.current_stream(device).cuda_stream), tag)
+    key = (dev, tag)
     capturing = torch.cuda.is_current_stream_capturing()
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
