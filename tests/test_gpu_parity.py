@@ -503,6 +503,9 @@ def test_graph_survives_a_larger_eager_call_and_a_reset():
     stack, hc, _, _ = _small_stack(window=96)
     T = 70
     xs = [bf(torch.randn(1, T, hc.hidden_size) * 0.5).to(DEV) for _ in range(4)]
+    torch.cuda.synchronize()
+    ops._WORKSPACES.clear()              # start from small buffers whatever ran before (no graph of an earlier test is alive)
+    ops._GRAPH_PINNED.clear()
     with torch.no_grad():
         c1, c2 = stack.allocate_inference_cache(1), stack.allocate_inference_cache(1)
         gs = GraphedStep(stack, c2, 1, T)
