@@ -138,6 +138,9 @@ def kernel_timings(device, chunk, window, only=None):
     add("gdn_chunk(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
         q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
         20, 27, "hbm", 24672.0 * T + sbytes)
+    add("gdn_chunk_fp8(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
+        q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
+        20, 0, "hbm", 24672.0 * T + sbytes)
     # SWA prefill: T queries over a full ring (W-1 cached keys) + T new keys; 8192*min(p+1,W) FLOP/token/layer
     kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
     pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
@@ -194,6 +197,9 @@ def kernel_timings(device, chunk, window, only=None):
     add("gdn_chunk@B=8", lambda: ops.chunk_gated_delta_rule(
         qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb),
         10, 0, "hbm", Bb * (24672.0 * T + sbytes))
+    add("gdn_chunk_fp8@B=8", lambda: ops.chunk_gated_delta_rule(
+        qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb,
+        mma_dtype="fp8_e4m3"), 10, 0, "hbm", Bb * (24672.0 * T + sbytes))
     kcb, vcb = rn(Bb, Hkv, C, d), rn(Bb, Hkv, C, d)
     qsb, knb, vnb = rn(Bb, T, Hq, d), rn(Bb, T, Hkv, d), rn(Bb, T, Hkv, d)
     add("swa_prefill@B=8", lambda: ops.swa_forward(qsb, knb, vnb, window=window, scaling=d ** -0.5, k_cache=kcb,
@@ -205,6 +211,9 @@ def kernel_timings(device, chunk, window, only=None):
     qL, kL, vL, gL, bL = gdn_inputs(TL)
     add("gdn_chunk@T=4096", lambda: ops.chunk_gated_delta_rule(
         qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
+        5, 0, "hbm", 24672.0 * TL + sbytes)
+    add("gdn_chunk_fp8@T=4096", lambda: ops.chunk_gated_delta_rule(
+        qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
         5, 0, "hbm", 24672.0 * TL + sbytes)
     qsL, knL, vnL = rn(B, TL, Hq, d), rn(B, TL, Hkv, d), rn(B, TL, Hkv, d)
     add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),

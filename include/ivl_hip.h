@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 1
+#define IVL_ABI_VERSION 2
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -37,6 +37,7 @@ extern "C" {
 #define IVL_BF16 0
 #define IVL_F16 1
 #define IVL_F32 2
+#define IVL_FP8_E4M3 3   /* OCP e4m3fn (gfx950); accepted only as `mma_dtype`: operand format of the MFMA products */
 
 /* error codes */
 #define IVL_OK 0
@@ -70,11 +71,16 @@ IVL_API int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, c
  *   state-scan + output pass (the per-chunk state snapshots never reach HBM).
  * `workspace` holds the pre-pass results; size from ivl_gdn_chunk_workspace_bytes.
  * Requires K == 128, V == 256 (the InfiniteVL head shape), any T >= 1 (zero-padded last chunk).
+ * mma_dtype = IVL_BF16: the reference's precision (bf16 operands at the reference's rounding points, fp32 accumulation).
+ * mma_dtype = IVL_FP8_E4M3 (BASELINE.json configs[4]; the reference has no such path): the four products of the serial
+ *   pass (w S, q S, k^T v_new, A v_new) take e4m3 operands -- w e^gamma, q_hat, k_hat e^{gl-gamma}, A, the state and v_new
+ *   are rounded to e4m3 (clamped to +-448) -- with fp32 accumulators, fp32 carried state and bf16 u / o: half the LDS and
+ *   L2 operand traffic of the scan.  Tolerance: tests/test_gpu_parity.py (fp8 section).
  * ------------------------------------------------------------------------------------------- */
 IVL_API size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V);
 IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
                       void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
-                      int B, int T, int H, int K, int V, float scale, int use_qk_l2norm,
+                      int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, int mma_dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

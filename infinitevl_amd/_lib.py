@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 
-IVL_BF16, IVL_F16, IVL_F32 = 0, 1, 2
+IVL_BF16, IVL_F16, IVL_F32, IVL_FP8_E4M3 = 0, 1, 2, 3
 IVL_OK = 0
 IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
 
@@ -74,7 +74,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_chunk_workspace_bytes.restype = sz
     lib.ivl_gdn_chunk_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.ivl_gdn_chunk_fwd.restype = i
-    lib.ivl_gdn_chunk_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, vp, sz, vp]
+    lib.ivl_gdn_chunk_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, i, vp, sz, vp]
     lib.ivl_gdn_gate_fwd.restype = i
     lib.ivl_gdn_gate_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp]
     lib.ivl_short_conv_fwd.restype = i

@@ -47,16 +47,21 @@ constexpr int GK = 128;       // key head dim
 constexpr int GV = 256;       // value head dim
 constexpr int G_SEG_CHUNKS = 64;   // chunks per workspace segment (4096 tokens)
 
-// ---- workspace record per (batch*head, chunk): byte offsets; [0, 57344) is a sequence of 56 fragment blocks ----
-constexpr int REC_WN = 0;          // -bf16(bf16(w) e^gamma)       blocks (m, s)  = 4 m + s    rows: time   contraction: k
-constexpr int REC_QH = 16384;      // q_hat                        blocks (m, s)  = 4 m + s    rows: time   contraction: k
-constexpr int REC_KDT = 32768;     // (k_hat e^{gl-gamma})^T       blocks (t, s2) = 2 t + s2   rows: k      contraction: time
-constexpr int REC_AQK = 49152;     // tril((q k^T) Gamma)          blocks (m, s2) = 2 m + s2   rows: time   contraction: time
-constexpr int REC_EG = 57344;      // f32 e^gamma[64]
-constexpr int REC_EGL = REC_EG + 256;    // f32 e^gamma_last
-constexpr int REC_U = 58368;       // bf16 u in the scan's accumulator layout: 8-byte piece ((slab, m, g), j) at
-                                   //   ((16 slab + 4 m + g) * 16 + j) * 8 = u[16m + 4g + 0..3][16 slab + j]   (32 KB)
-constexpr size_t REC_STRIDE = 91136;     // 89 pieces of 1 KB
+// ---- workspace record per (batch*head, chunk) ------------------------------------------------------------------
+// 56 fragment blocks (1 KB each in bf16, 512 B in fp8 e4m3), then e^gamma, then u (always bf16: it is an accumulator input)
+//   WN  : -(bf16(w) e^gamma)            blocks (m, s)  = 4 m + s    rows: time   contraction: k
+//   QH  : q_hat                         blocks (m, s)  = 4 m + s    rows: time   contraction: k
+//   KDT : (k_hat e^{gl-gamma})^T        blocks (t, s2) = 2 t + s2   rows: k      contraction: time
+//   AQK : tril((q k^T) Gamma)           blocks (m, s2) = 2 m + s2   rows: time   contraction: time
+//   EG  : f32 e^gamma[64]; EGL: f32 e^gamma_last
+//   U   : bf16 u in the scan's accumulator layout: 8-byte piece ((slab, m, g), j) at ((16 slab + 4 m + g) * 16 + j) * 8
+//         = u[16m + 4g + 0..3][16 slab + j]   (32 KB)
+template <bool F8>
+struct Rec {
+  static constexpr int BLK = F8 ? 512 : 1024;       // bytes per fragment block; a piece = BLK / 64 bytes per lane
+  static constexpr int WN = 0, QH = 16 * BLK, KDT = 32 * BLK, AQK = 48 * BLK, EG = 56 * BLK, EGL = EG + 256, U = EG + 1024;
+  static constexpr size_t STRIDE = U + 32768;       // bf16: 91,136   fp8: 62,464
+};
 
 __device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) {
   mfma_bf16x8 r;
@@ -66,6 +71,24 @@ __device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) {
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ u32x4 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
   return u32x4{pack2bf(a0, a1), pack2bf(a2, a3), pack2bf(a4, a5), pack2bf(a6, a7)};
+}
+
+// four floats -> four OCP e4m3 bytes (gfx950 hardware conversion; clamped to the finite range +-448 first)
+__device__ __forceinline__ unsigned int pack4_fp8(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned int)r;
+}
+// piece `idx` (lane-linear position inside a sequence of fragment blocks) <- eight consecutive contraction slots
+template <bool F8>
+__device__ __forceinline__ void put_piece(unsigned char* base, int idx, float a0, float a1, float a2, float a3, float a4, float a5,
+                                          float a6, float a7) {
+  if (F8) *(u32x2*)(base + idx * 8) = u32x2{pack4_fp8(a0, a1, a2, a3), pack4_fp8(a4, a5, a6, a7)};
+  else *(u32x4*)(base + idx * 16) = pack8(a0, a1, a2, a3, a4, a5, a6, a7);
 }
 
 // ==================================================================================================
@@ -118,10 +141,12 @@ __device__ __forceinline__ u32x4 frag_tr32(const bf16_t* X, int ld, int k0, int 
   return u32x4{w0.x, w0.y, w1.x, w1.y};
 }
 
+template <bool F8>
 __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using R = Rec<F8>;
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
   bf16_t* s_kb = (bf16_t*)(smem + P_KB);
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   const int b = bh / H, h = bh % H;
   const int t0 = t_seg0 + ci * GC;            // first token of the chunk
   const int nvalid = min(GC, T - t0);
-  unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * REC_STRIDE;
+  unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * R::STRIDE;
 
   // ---- P0: every global load of the chunk is issued up front (clamped rows, zeroed later) ------------------
   const int oct = tid & 15, r0 = tid >> 4;         // thread -> rows r0, r0 + 32; 16-byte column octet
@@ -184,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     s_eg[lane] = e;
     s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
     s_beta[lane] = bv;                               // 0 for padded rows
-    ((float*)(rec + REC_EG))[lane] = e;
-    if (lane == 0) *(float*)(rec + REC_EGL) = __expf(gl);
+    ((float*)(rec + R::EG))[lane] = e;
+    if (lane == 0) *(float*)(rec + R::EGL) = __expf(gl);
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
 #pragma unroll
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();                                   // B1
   IVL_T(tp1);
 
-  // Copy-out of the two operands that are plain re-orderings of the LDS tiles, 16-byte piece `idx` of 2048:
+  // Copy-out of the two operands that are plain re-orderings of the LDS tiles, piece `idx` of 2048:
   //   [0,1024)    QH : piece (block 4m+s, g, i) = q_hat[16m+i][32s + {4g..4g+3, 16+4g..+3}]
   //   [1024,2048) KDT: piece (block 2t+s2, g, i) = k_hat[32s2 + {4g.., 16+4g..}][16t+i] * dec[time]  (LDS transpose read)
   auto copy_piece = [&](int idx) {
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const int blk = idx >> 6, m = blk >> 2, s = blk & 3;
       const bf16_t* src = s_qh + (16 * m + i) * P_LDK + 32 * s + 4 * gg;
       const u32x2 lo = *(const u32x2*)src, hi2 = *(const u32x2*)(src + 16);
-      *(u32x4*)(rec + REC_QH + idx * 16) = u32x4{lo.x, lo.y, hi2.x, hi2.y};
+      put_piece<F8>(rec + R::QH, idx, bflo(lo.x), bfhi(lo.x), bflo(lo.y), bfhi(lo.y), bflo(hi2.x), bfhi(hi2.x), bflo(hi2.y), bfhi(hi2.y));
     } else {
       const int id2 = idx - 1024, blk = id2 >> 6, t = blk >> 1, s2 = blk & 1;
       const int time0 = 32 * s2 + 4 * gg;
@@ -242,9 +267,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       u32x2 w0, w1;
       __builtin_memcpy(&w0, &a0, 8);
       __builtin_memcpy(&w1, &a1, 8);
-      *(u32x4*)(rec + REC_KDT + id2 * 16) =
-          pack8(bflo(w0.x) * d0[0], bfhi(w0.x) * d0[1], bflo(w0.y) * d0[2], bfhi(w0.y) * d0[3],
-                bflo(w1.x) * d1[0], bfhi(w1.x) * d1[1], bflo(w1.y) * d1[2], bfhi(w1.y) * d1[3]);
+      put_piece<F8>(rec + R::KDT, id2, bflo(w0.x) * d0[0], bfhi(w0.x) * d0[1], bflo(w0.y) * d0[2], bfhi(w0.y) * d0[3],
+                    bflo(w1.x) * d1[0], bfhi(w1.x) * d1[1], bflo(w1.y) * d1[2], bfhi(w1.y) * d1[3]);
     }
   };
 
@@ -288,15 +312,15 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
         val[4 * a + c] = i >= j ? acc[4 * a + c] * __expf(gi - gj[c]) : 0.f;
       }
     }
-    unsigned char* blk = rec + REC_AQK + ((2 * mi + (l31 >> 4)) * 2 + nj) * 1024;
+    const int pc0 = ((2 * mi + (l31 >> 4)) * 2 + nj) * 64 + hi * 16 + (l31 & 15);        // piece (block, g = hi, i)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      *(u32x4*)(blk + ((hi + 2 * p) * 16 + (l31 & 15)) * 16) =
-          pack8(val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p], val[10 + 4 * p], val[11 + 4 * p]);
+      put_piece<F8>(rec + R::AQK, pc0 + 32 * p, val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p],
+                    val[10 + 4 * p], val[11 + 4 * p]);
   } else {
     // blocks (m < 2, s2 = 1) of Aqk lie strictly above the diagonal: zeros
     const int t2 = tid - 384;                        // 0..127
-    *(u32x4*)(rec + REC_AQK + (2 * (t2 >> 6) + 1) * 1024 + (t2 & 63) * 16) = u32x4{0u, 0u, 0u, 0u};
+    put_piece<F8>(rec + R::AQK, (2 * (t2 >> 6) + 1) * 64 + (t2 & 63), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int z = 0; z < 4; ++z) copy_piece(t2 + 128 * z);                 // QH pieces 0..511
   }
@@ -436,12 +460,12 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(kbf), mf(twf), acc, 0, 0, 0);
     }
     const float negeg = -s_eg[i];
-    unsigned char* blk = rec + REC_WN + ((2 * mi + (l31 >> 4)) * 4 + s) * 1024;
+    const int pc0 = ((2 * mi + (l31 >> 4)) * 4 + s) * 64 + hi * 16 + (l31 & 15);
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      *(u32x4*)(blk + ((hi + 2 * p) * 16 + (l31 & 15)) * 16) =
-          pack8(bf_round(acc[4 * p]) * negeg, bf_round(acc[4 * p + 1]) * negeg, bf_round(acc[4 * p + 2]) * negeg, bf_round(acc[4 * p + 3]) * negeg,
-                bf_round(acc[8 + 4 * p]) * negeg, bf_round(acc[9 + 4 * p]) * negeg, bf_round(acc[10 + 4 * p]) * negeg, bf_round(acc[11 + 4 * p]) * negeg);
+      put_piece<F8>(rec + R::WN, pc0 + 32 * p, bf_round(acc[4 * p]) * negeg, bf_round(acc[4 * p + 1]) * negeg, bf_round(acc[4 * p + 2]) * negeg,
+                    bf_round(acc[4 * p + 3]) * negeg, bf_round(acc[8 + 4 * p]) * negeg, bf_round(acc[9 + 4 * p]) * negeg,
+                    bf_round(acc[10 + 4 * p]) * negeg, bf_round(acc[11 + 4 * p]) * negeg);
   }
   // ---- P4c: u = Tu (beta v): wave -> 32 value columns, both 32-row time tiles; a lane owns one column and, per
   //           group of four accumulator registers, four consecutive times = one 8-byte piece of the scan's layout ---
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
     }
     const int col = 32 * wave_u + l31;
-    unsigned char* ub = rec + REC_U + (size_t)(col >> 4) * 2048 + (col & 15) * 8;
+    unsigned char* ub = rec + R::U + (size_t)(col >> 4) * 2048 + (col & 15) * 8;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -479,13 +503,18 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 // ==================================================================================================
 // (2) serial scan + output
 // ==================================================================================================
-// LDS: two images of 65 KB.  Image bytes [0, 58368) mirror the record (Wn, q_hat, Kd^T, Aqk, e^gamma); the workgroup's
-// 8 KB slab of u follows.  H1 = {Wn, q_hat, e^gamma, u slab} is read in the first half of a chunk, H2 = {Kd^T, Aqk} in
-// the second.
-constexpr int IMG_U = REC_U;                               // NCW compute waves x 2 KB
-constexpr int IMG_BYTES = IMG_U + 8192;                    // 66,560
-constexpr int SCAN_LDS = 2 * IMG_BYTES;                    // 133,120
-static_assert(SCAN_LDS <= 160 * 1024, "scan LDS budget");
+// LDS: two operand images.  Image bytes [0, Rec::U) mirror the record (Wn, q_hat, Kd^T, Aqk, e^gamma); the workgroup's
+// slab of u (2 KB per pair) follows.  H1 = {Wn, q_hat, e^gamma, u slab} is read in the first half of a chunk,
+// H2 = {Kd^T, Aqk} in the second.  bf16: 65 KB per image; fp8: 37 KB.
+template <bool F8>
+struct Img {
+  static constexpr int U = Rec<F8>::U;
+  static constexpr int BYTES = U + 8192;
+  static constexpr int XCH = 2 * BYTES;                    // then per pair: sb (4 fragments) | v_new (2 fragments)
+  static constexpr int XCH_PAIR = 6 * Rec<F8>::BLK;
+};
+__host__ __device__ constexpr int scan_lds_bytes(int ncw, bool f8) { return f8 ? Img<true>::XCH + ncw * Img<true>::XCH_PAIR : Img<false>::XCH + ncw * Img<false>::XCH_PAIR; }
+static_assert(scan_lds_bytes(4, false) <= 160 * 1024, "scan LDS budget");
 
 // LDS-DMA, four consecutive 1 KB pieces: global [gsrc + 1024 p + 16 lane] -> LDS [lds_dst + 1024 p + 16 lane], p = 0..3
 // (the instruction offset is added to both addresses).  gsrc and lds_dst are wave-uniform (SGPRs); hipcc does not count
@@ -511,24 +540,34 @@ __device__ __forceinline__ void dma1(const unsigned char* gsrc, unsigned int lds
 // workgroup barrier that waits for this wave's LDS traffic only (no vector-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Loader wave L (0 / 1) issues every other DMA statement of a half image.
-//   H1(ci): 4 x dma4 Wn, 4 x dma4 q_hat, 2 x dma4 u slab, 1 piece e^gamma  -> L0: 5 dma4 + 1 = 21 pieces, L1: 5 dma4 = 20
-//   H2(ci): 4 x dma4 Kd^T, 2 x dma4 Aqk                                    -> 12 pieces each
-template <int L, int NCW>
-__device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, int slab_wg, unsigned int lane16) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    dma4(rec + REC_WN + (2 * q + L) * 4096, img + (unsigned int)(REC_WN + (2 * q + L) * 4096), lane16);      // Wn | q_hat: 8 groups of 4 KB
-  }
-  if (NCW == 4) dma4(rec + REC_U + slab_wg * 8192 + L * 4096, img + (unsigned int)(IMG_U + L * 4096), lane16);
-  else if (L == 1) dma4(rec + REC_U + slab_wg * 4096, img + (unsigned int)IMG_U, lane16);
-  if (L == 0) dma1(rec + REC_EG, img + (unsigned int)REC_EG, lane16);
+// The two loader waves take the 4 KB DMA units of a half image alternately (unit u -> loader u & 1):
+//   H1(ci): Wn | q_hat (contiguous: 8 units in bf16, 4 in fp8), the workgroup's u slab (NCW / 2 units), + 1 piece e^gamma (loader 0)
+//   H2(ci): Kd^T | Aqk (contiguous: 6 units in bf16, 3 in fp8)
+__host__ __device__ constexpr int h1_units(int ncw, bool f8) { return (f8 ? 4 : 8) + ncw / 2; }
+__host__ __device__ constexpr int h2_units(bool f8) { return f8 ? 3 : 6; }
+__host__ __device__ constexpr int loader_n1(int L, int ncw, bool f8) {       // pieces of H1 issued by loader L
+  return 4 * (L == 0 ? (h1_units(ncw, f8) + 1) / 2 : h1_units(ncw, f8) / 2) + (L == 0 ? 1 : 0);
 }
-template <int L>
-__device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int img, unsigned int lane16) {
+__host__ __device__ constexpr int loader_n2(int L, bool f8) { return 4 * (L == 0 ? (h2_units(f8) + 1) / 2 : h2_units(f8) / 2); }
+
+template <int L, int NCW, bool F8>
+__device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, int slab_wg, unsigned int lane16) {
+  using R = Rec<F8>;
+  constexpr int NA = F8 ? 4 : 8;                   // units of Wn | q_hat
 #pragma unroll
-  for (int q = 0; q < 3; ++q)
-    dma4(rec + REC_KDT + (2 * q + L) * 4096, img + (unsigned int)(REC_KDT + (2 * q + L) * 4096), lane16);              // Kd^T | Aqk: 6 groups of 4 KB
+  for (int u = 0; u < NA; ++u)
+    if ((u & 1) == L) dma4(rec + R::WN + u * 4096, img + (unsigned int)(R::WN + u * 4096), lane16);
+#pragma unroll
+  for (int u = 0; u < NCW / 2; ++u)
+    if (((NA + u) & 1) == L) dma4(rec + R::U + slab_wg * (NCW * 2048) + u * 4096, img + (unsigned int)(Img<F8>::U + u * 4096), lane16);
+  if (L == 0) dma1(rec + R::EG, img + (unsigned int)R::EG, lane16);
+}
+template <int L, bool F8>
+__device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int img, unsigned int lane16) {
+  using R = Rec<F8>;
+#pragma unroll
+  for (int u = 0; u < h2_units(F8); ++u)
+    if ((u & 1) == L) dma4(rec + R::KDT + u * 4096, img + (unsigned int)(R::KDT + u * 4096), lane16);
 }
 
 // Barrier protocol (every wave of the workgroup executes the same sequence P, T(0), M(0), T(1), M(1), ...):
@@ -537,22 +576,22 @@ __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int i
 //   M(ci) : H1(ci + 1) has landed;  every wave has read H1(ci)            -> H1(ci + 2) may be issued (image ci & 1)
 // so each half image is requested one whole chunk before its barrier.  vmcnt retires in issue order: "landed" = at most
 // the pieces issued AFTER the awaited half are still outstanding.
-template <int L, int NCW>
+template <int L, int NCW, bool F8>
 __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, int slab_wg, unsigned int lds0, unsigned int lane16) {
-  // pieces per half image and loader: H1 = 16 (Wn, q_hat) + u slab + e^gamma, H2 = 12
-  constexpr int N1 = NCW == 4 ? (L == 0 ? 21 : 20) : (L == 0 ? 17 : 20), N2 = 12;
+  constexpr int N1 = loader_n1(L, NCW, F8), N2 = loader_n2(L, F8);          // pieces per half image issued by this loader
+  static_assert(N1 + N2 < 64, "vmcnt immediate");
   auto wait_le = [&](int n) {                                   // s_waitcnt vmcnt(n), n a compile-time constant per call site
     if (n == N1 + N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1 + N2) : "memory");
     else if (n == N1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
     else if (n == N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  auto rec = [&](int ci) { return ws_bh + (size_t)ci * REC_STRIDE; };
-  auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * IMG_BYTES); };
-  load_h1<L, NCW>(rec(0), img(0), slab_wg, lane16);
-  load_h2<L>(rec(0), img(0), lane16);
+  auto rec = [&](int ci) { return ws_bh + (size_t)ci * Rec<F8>::STRIDE; };
+  auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * Img<F8>::BYTES); };
+  load_h1<L, NCW, F8>(rec(0), img(0), slab_wg, lane16);
+  load_h2<L, F8>(rec(0), img(0), lane16);
   if (nt_seg > 1) {
-    load_h1<L, NCW>(rec(1), img(1), slab_wg, lane16);
+    load_h1<L, NCW, F8>(rec(1), img(1), slab_wg, lane16);
     wait_le(N1 + N2);                                           // H2(0) + H1(1) behind H1(0)
   } else {
     wait_le(N2);                                                // H2(0) behind H1(0)
@@ -563,11 +602,11 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     else wait_le(0);
     lds_barrier();                                             // T(ci)
     if (ci + 1 < nt_seg) {
-      load_h2<L>(rec(ci + 1), img(ci + 1), lane16);
+      load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
       wait_le(N2);                                             // H2(ci+1) behind H1(ci+1)
     }
     lds_barrier();                                             // M(ci)
-    if (ci + 2 < nt_seg) load_h1<L, NCW>(rec(ci + 2), img(ci + 2), slab_wg, lane16);
+    if (ci + 2 < nt_seg) load_h1<L, NCW, F8>(rec(ci + 2), img(ci + 2), slab_wg, lane16);
   }
 }
 
@@ -579,16 +618,37 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
 // scaling and the stores run beside it.  sb / v_new cross through 6 KB of LDS per pair, ordered by the two barriers the
 // loader protocol needs anyway.  NCW = 4: 64 columns per workgroup (operand image shared by four pairs: least L2 traffic);
 // NCW = 2: 32 columns, twice the workgroups -- used while the grid would otherwise leave most of the chip idle.
-constexpr int XCH_SB = SCAN_LDS;                            // per pair: sb 4 KB (4 fragments) | v_new 2 KB (2 fragments)
-__host__ __device__ constexpr int scan_lds_bytes(int ncw) { return SCAN_LDS + ncw * 6144; }
-static_assert(scan_lds_bytes(4) <= 160 * 1024, "scan LDS budget");
+// fp8 (e4m3) operand variant (F8): the four A-operand matrices arrive as 512-byte blocks, the state and v_new are
+// converted to e4m3 for the products (v_mfma_f32_16x16x32_fp8_fp8: same lane layout, 8 bytes per fragment); accumulators,
+// the carried state, u and the output stay fp32 / bf16.  Half the LDS and L2 traffic of the scan.
+template <bool F8> struct FragT { typedef u32x4 type; };
+template <> struct FragT<true> { typedef u32x2 type; };
+template <bool F8>
+__device__ __forceinline__ f32x4 mma16(typename FragT<F8>::type a, typename FragT<F8>::type b, f32x4 c) {
+  if constexpr (F8) {
+    long la, lb;
+    __builtin_memcpy(&la, &a, 8);
+    __builtin_memcpy(&lb, &b, 8);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(a), mf(b), c, 0, 0, 0);
+  }
+}
+template <bool F8>
+__device__ __forceinline__ typename FragT<F8>::type to_frag(f32x4 lo, f32x4 hi) {     // slots 0..3 <- lo, 4..7 <- hi
+  if constexpr (F8) return u32x2{pack4_fp8(lo[0], lo[1], lo[2], lo[3]), pack4_fp8(hi[0], hi[1], hi[2], hi[3])};
+  else return pack8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+}
 
-template <int NCW>
+template <int NCW, bool F8>
 __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
     const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
     int T, int H, int t_seg0, int nt_seg, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  using R = Rec<F8>;
+  using frag_t = typename FragT<F8>::type;
+  constexpr int IMG_BYTES = Img<F8>::BYTES, IMG_U = Img<F8>::U, BLK = R::BLK;
 
   IVL_T(ts0);
   IVL_TVAR(t_bar); IVL_TVAR(t_bar2); IVL_TVAR(t_h1); IVL_TVAR(t_h2); IVL_TVAR(t_sb);
@@ -600,29 +660,30 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh % H;
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)smem);
-  const unsigned int lane16 = lane * 16;
-  const unsigned char* ws_bh = ws + (size_t)bh * nt_seg * REC_STRIDE;
+  const unsigned int lane16 = lane * 16;                          // DMA piece offset
+  const int lanef = lane * (BLK / 64);                            // fragment offset inside a block
+  const unsigned char* ws_bh = ws + (size_t)bh * nt_seg * R::STRIDE;
 
   if (wave_u >= 2 * NCW) {                                      // ---- loader waves ----
-    if (wave_u == 2 * NCW) scan_loader<0, NCW>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
-    else scan_loader<1, NCW>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    if (wave_u == 2 * NCW) scan_loader<0, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    else scan_loader<1, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
     return;
   }
   const int pair = wave_u < NCW ? wave_u : wave_u - NCW;
   const int v0 = (blockIdx.y * NCW + pair) * 16;                // first state column of this pair
-  unsigned char* xsb = smem + XCH_SB + pair * 6144;             // sb: 4 fragments x 1 KB, lane-linear
-  unsigned char* xvn = xsb + 4096;                              // v_new: 2 fragments
-  auto frag = [&](const unsigned char* im, int off, int idx) { return *(const u32x4*)(im + off + idx * 1024 + lane16); };
+  unsigned char* xsb = smem + Img<F8>::XCH + pair * Img<F8>::XCH_PAIR;   // sb: 4 fragment blocks, lane-linear
+  unsigned char* xvn = xsb + 4 * BLK;                                    // v_new: 2 fragment blocks
+  auto frag = [&](const unsigned char* im, int off, int idx) { return *(const frag_t*)(im + off + idx * BLK + lanef); };
 
   if (wave_u >= NCW) {
     // =========================== output wave ===========================
-    u32x4 fq[16];
+    frag_t fq[16];
     float egv[4];
     lds_barrier();                       // P: H1(0) has landed
 #pragma unroll
-    for (int i = 0; i < 16; ++i) fq[i] = frag(smem, REC_QH, i);
+    for (int i = 0; i < 16; ++i) fq[i] = frag(smem, R::QH, i);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(smem + REC_EG + (16 * m + j) * 4);
+    for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(smem + R::EG + (16 * m + j) * 4);
     bf16_t* orow = o + (((size_t)b * T + t_seg0 + j) * H + h) * GV + v0 + 4 * g;
     const size_t ostep = (size_t)16 * H * GV;                   // 16 tokens further
     for (int ci = 0; ci < nt_seg; ++ci) {
@@ -630,11 +691,11 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
       const unsigned char* img_next = smem + ((ci + 1) & 1) * IMG_BYTES;
       const int tc0 = t_seg0 + ci * GC;
       lds_barrier();                     // T(ci): sb(ci) published, H2(ci) landed
-      u32x4 sb[4], fa[6];
+      frag_t sb[4], fa[6];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sb[s] = *(const u32x4*)(xsb + s * 1024 + lane16);
-      fa[0] = frag(img, REC_AQK, 0); fa[1] = frag(img, REC_AQK, 2); fa[2] = frag(img, REC_AQK, 4);
-      fa[3] = frag(img, REC_AQK, 5); fa[4] = frag(img, REC_AQK, 6); fa[5] = frag(img, REC_AQK, 7);
+      for (int s = 0; s < 4; ++s) sb[s] = *(const frag_t*)(xsb + s * BLK + lanef);
+      fa[0] = frag(img, R::AQK, 0); fa[1] = frag(img, R::AQK, 2); fa[2] = frag(img, R::AQK, 4);
+      fa[3] = frag(img, R::AQK, 5); fa[4] = frag(img, R::AQK, 6); fa[5] = frag(img, R::AQK, 7);
       // (q_hat S)^T: lane (g, j) register r <-> column v0 + 4g + r, time 16m + j
       f32x4 accO[4];
 #pragma unroll
@@ -643,24 +704,24 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          accO[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(sb[s]), mf(fq[4 * m + s]), accO[m], 0, 0, 0);
+          accO[m] = mma16<F8>(sb[s], fq[4 * m + s], accO[m]);
 #pragma unroll
       for (int m = 0; m < 4; ++m) accO[m] *= egv[m];
       lds_barrier();                     // M(ci): v_new(ci) published, H1(ci+1) landed
-      u32x4 vn[2];
-      vn[0] = *(const u32x4*)(xvn + lane16);
-      vn[1] = *(const u32x4*)(xvn + 1024 + lane16);
+      frag_t vn[2];
+      vn[0] = *(const frag_t*)(xvn + lanef);
+      vn[1] = *(const frag_t*)(xvn + BLK + lanef);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) fq[i] = frag(img_next, REC_QH, i);        // next chunk (stale but harmless after the last one)
+      for (int i = 0; i < 16; ++i) fq[i] = frag(img_next, R::QH, i);        // next chunk (stale but harmless after the last one)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(img_next + REC_EG + (16 * m + j) * 4);
+      for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(img_next + R::EG + (16 * m + j) * 4);
       // + v_new^T Aqk^T (the blocks (m < 2, s2 = 1) lie strictly above the diagonal)
-      accO[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[0]), accO[0], 0, 0, 0);
-      accO[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[1]), accO[1], 0, 0, 0);
-      accO[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[2]), accO[2], 0, 0, 0);
-      accO[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[0]), mf(fa[4]), accO[3], 0, 0, 0);
-      accO[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[1]), mf(fa[3]), accO[2], 0, 0, 0);
-      accO[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(vn[1]), mf(fa[5]), accO[3], 0, 0, 0);
+      accO[0] = mma16<F8>(vn[0], fa[0], accO[0]);
+      accO[1] = mma16<F8>(vn[0], fa[1], accO[1]);
+      accO[2] = mma16<F8>(vn[0], fa[2], accO[2]);
+      accO[3] = mma16<F8>(vn[0], fa[4], accO[3]);
+      accO[2] = mma16<F8>(vn[1], fa[3], accO[2]);
+      accO[3] = mma16<F8>(vn[1], fa[5], accO[3]);
       if (tc0 + GC <= T) {               // full chunk (wave-uniform): four unconditional 8-byte row stores
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -704,15 +765,15 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
     }
   }
   // Wn fragments, u and e^gamma_L of the NEXT chunk are loop-carried: requested a phase ahead of their use
-  u32x4 fw[16];
+  frag_t fw[16];
   u32x2 uu[4];
   float egl;
   auto load_h1_frags = [&](const unsigned char* im) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) fw[i] = frag(im, REC_WN, i);
+    for (int i = 0; i < 16; ++i) fw[i] = frag(im, R::WN, i);
 #pragma unroll
     for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(im + IMG_U + pair * 2048 + m * 512 + lane * 8);
-    egl = *(const float*)(im + REC_EGL);
+    egl = *(const float*)(im + R::EGL);
   };
   lds_barrier();                         // P: H1(0) has landed
   load_h1_frags(smem);
@@ -722,18 +783,18 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
     const unsigned char* img_next = smem + ((ci + 1) & 1) * IMG_BYTES;
     IVL_T(tc_0);
     // ---- B-operand fragments: the state (bf16); published for the output wave --------------------------------------
-    u32x4 sb[4];
+    frag_t sb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      sb[s] = pack8(S[2 * s][0], S[2 * s][1], S[2 * s][2], S[2 * s][3], S[2 * s + 1][0], S[2 * s + 1][1], S[2 * s + 1][2], S[2 * s + 1][3]);
-      *(u32x4*)(xsb + s * 1024 + lane16) = sb[s];
+      sb[s] = to_frag<F8>(S[2 * s], S[2 * s + 1]);
+      *(frag_t*)(xsb + s * BLK + lanef) = sb[s];
     }
     IVL_T(tc_a);
     lds_barrier();                       // T(ci): H2 of this chunk has landed
     IVL_T(tc_b);
-    u32x4 fk[16];
+    frag_t fk[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) fk[i] = frag(img, REC_KDT, i);              // land under the 16 MFMAs below
+    for (int i = 0; i < 16; ++i) fk[i] = frag(img, R::KDT, i);              // land under the 16 MFMAs below
     // ---- v_new = u + Wn S   (time tiles m, lane (g, j) register r <-> time 16m + 4g + r, column j); u (bf16) is the C input
     f32x4 accV[4];
 #pragma unroll
@@ -742,15 +803,14 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        accV[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(fw[4 * m + s]), mf(sb[s]), accV[m], 0, 0, 0);
+        accV[m] = mma16<F8>(fw[4 * m + s], sb[s], accV[m]);
 #pragma unroll
     for (int t = 0; t < 8; ++t) S[t] *= egl;
-    u32x4 vn[2];
+    frag_t vn[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      vn[s2] = pack8(accV[2 * s2][0], accV[2 * s2][1], accV[2 * s2][2], accV[2 * s2][3],
-                     accV[2 * s2 + 1][0], accV[2 * s2 + 1][1], accV[2 * s2 + 1][2], accV[2 * s2 + 1][3]);
-      *(u32x4*)(xvn + s2 * 1024 + lane16) = vn[s2];
+      vn[s2] = to_frag<F8>(accV[2 * s2], accV[2 * s2 + 1]);
+      *(frag_t*)(xvn + s2 * BLK + lanef) = vn[s2];
     }
     IVL_T(tc_c);
     lds_barrier();                       // M(ci): H1 of the next chunk has landed; every wave is done with H1 of this one
@@ -761,7 +821,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(fk[2 * t + s2]), mf(vn[s2]), S[t], 0, 0, 0);
+        S[t] = mma16<F8>(fk[2 * t + s2], vn[s2], S[t]);
     IVL_T(tc_e);
     IVL_TACC(t_bar, tc_b, tc_a); IVL_TACC(t_bar2, tc_d, tc_c); IVL_TACC(t_h1, tc_c, tc_b); IVL_TACC(t_h2, tc_e, tc_d); IVL_TACC(t_sb, tc_a, tc_0);
   }
@@ -804,39 +864,31 @@ static void gdn_chunk_init_device() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 63], [] {
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_BYTES);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_lds_bytes(4));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_lds_bytes(2));
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, false>, attr, scan_lds_bytes(4, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2, false>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, true>, attr, scan_lds_bytes(4, true));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2, true>, attr, scan_lds_bytes(2, true));
   });
 }
 
 extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V) {
   if (B <= 0 || T <= 0 || H <= 0 || K != GK || V != GV) return 0;
   const int NT = (T + GC - 1) / GC;
-  size_t bytes = (size_t)B * H * seg_chunks(NT) * REC_STRIDE;
+  size_t bytes = (size_t)B * H * seg_chunks(NT) * Rec<false>::STRIDE;          // the fp8 records are smaller
   if (NT > G_SEG_CHUNKS) bytes += (size_t)B * H * GK * GV * sizeof(float);   // fp32 state carried between segments
   return bytes;
 }
 
-extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
-                                 void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
-                                 int B, int T, int H, int K, int V, float scale, int use_qk_l2norm,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
-  IVL_REQUIRE(q && k && v && g && beta && o, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: NULL pointer");
-  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
-  IVL_REQUIRE(K == GK && V == GV, IVL_ERR_UNSUPPORTED, "ivl_gdn_chunk_fwd: built for K=128,V=256 (got %d,%d)", K, V);
-  IVL_REQUIRE((h0 == nullptr || h0_dtype == IVL_F32 || h0_dtype == IVL_BF16) &&
-              (ht == nullptr || ht_dtype == IVL_F32 || ht_dtype == IVL_BF16),
-              IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: state dtype must be IVL_F32 or IVL_BF16");
-  const size_t need = ivl_gdn_chunk_workspace_bytes(B, T, H, K, V);
-  IVL_REQUIRE(workspace != nullptr && workspace_bytes >= need, IVL_ERR_WORKSPACE,
-              "ivl_gdn_chunk_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
-  gdn_chunk_init_device();
-  hipStream_t st = (hipStream_t)stream;
+template <bool F8>
+static int gdn_chunk_launch(const void* q, const void* k, const void* v, const float* g, const void* beta, void* o,
+                            const void* h0, int h0_dtype, void* ht, int ht_dtype, int B, int T, int H, float scale,
+                            int use_qk_l2norm, unsigned char* wsb, hipStream_t st) {
   const int NT = (T + GC - 1) / GC;
   const int segc = seg_chunks(NT);
-  unsigned char* wsb = (unsigned char*)workspace;
-  float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * REC_STRIDE) : nullptr;
+  float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * Rec<false>::STRIDE) : nullptr;
   int ncw = B * H * 4 <= 128 ? 2 : 4;          // 32-column workgroups while 64-column ones would leave half the CUs idle
 #ifdef IVL_TRACE
   if (g_scan_ncw) ncw = g_scan_ncw;
@@ -844,7 +896,7 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
     const bool first = c0 == 0, last = c0 + nseg >= NT;
-    hipLaunchKernelGGL(gdn_chunk_prepare_kernel, dim3(nseg, B * H), dim3(512), P_BYTES, st,
+    hipLaunchKernelGGL(gdn_chunk_prepare_kernel<F8>, dim3(nseg, B * H), dim3(512), P_BYTES, st,
                        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb, T, H, c0 * GC, nseg,
                        use_qk_l2norm);
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
@@ -854,13 +906,36 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
     if (ncw == 2)
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2>), dim3(B * H, 8), dim3(384), scan_lds_bytes(2), st, (const unsigned char*)wsb,
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2, F8>), dim3(B * H, 8), dim3(384), scan_lds_bytes(2, F8), st, (const unsigned char*)wsb,
                          (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     else
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4>), dim3(B * H, 4), dim3(640), scan_lds_bytes(4), st, (const unsigned char*)wsb,
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4, F8>), dim3(B * H, 4), dim3(640), scan_lds_bytes(4, F8), st, (const unsigned char*)wsb,
                          (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
   }
   return IVL_OK;
+}
+
+extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                                 void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                                 int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, int mma_dtype,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  IVL_REQUIRE(q && k && v && g && beta && o, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: NULL pointer");
+  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
+  IVL_REQUIRE(K == GK && V == GV, IVL_ERR_UNSUPPORTED, "ivl_gdn_chunk_fwd: built for K=128,V=256 (got %d,%d)", K, V);
+  IVL_REQUIRE((h0 == nullptr || h0_dtype == IVL_F32 || h0_dtype == IVL_BF16) &&
+              (ht == nullptr || ht_dtype == IVL_F32 || ht_dtype == IVL_BF16),
+              IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fwd: state dtype must be IVL_F32 or IVL_BF16");
+  IVL_REQUIRE(mma_dtype == IVL_BF16 || mma_dtype == IVL_FP8_E4M3, IVL_ERR_INVALID_ARG,
+              "ivl_gdn_chunk_fwd: mma_dtype must be IVL_BF16 or IVL_FP8_E4M3 (got %d)", mma_dtype);
+  const size_t need = ivl_gdn_chunk_workspace_bytes(B, T, H, K, V);
+  IVL_REQUIRE(workspace != nullptr && workspace_bytes >= need, IVL_ERR_WORKSPACE,
+              "ivl_gdn_chunk_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+  gdn_chunk_init_device();
+  if (mma_dtype == IVL_FP8_E4M3)
+    return gdn_chunk_launch<true>(q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
+                                  (unsigned char*)workspace, (hipStream_t)stream);
+  return gdn_chunk_launch<false>(q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
+                                 (unsigned char*)workspace, (hipStream_t)stream);
 }

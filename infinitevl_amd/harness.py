@@ -198,6 +198,15 @@ class InfiniteVLTextStack(nn.Module):
             layer.mlp.fuse_()
         return self
 
+    def set_mma_dtype(self, mma_dtype) -> "InfiniteVLTextStack":
+        """Operand format of the mixers' MFMA products: None / "bf16" = the reference's precision; "fp8_e4m3" =
+        BASELINE.json configs[4] (e4m3 operands in the Gated DeltaNet chunk scan and the SWA decode step; fp32
+        accumulation and state).  Graphs captured before the switch keep the format they were captured with."""
+        ops.mma_code(mma_dtype)                      # validates
+        for layer in self.layers:
+            layer.self_attn.mma_dtype = mma_dtype
+        return self
+
     def allocate_inference_cache(self, batch_size: int = 1, dtype: Optional[torch.dtype] = None,
                                  zero_init: bool = False) -> StaticCachePrealloc:
         p_ = next(self.parameters())

@@ -74,6 +74,7 @@ class InfiniteVLSelfAttention(nn.Module):
                                if config.layer_types[self.layer_idx] == "sliding_attention" else None)
         self.rotary_emb = InfiniteVLRotaryEmbedding(config=config)
         self._fused_w = self._fused_b = None
+        self.mma_dtype = None           # None = bf16 operands; "fp8_e4m3": single-token decode products on e4m3 (configs[4])
 
     @torch.no_grad()
     def fuse_(self) -> "InfiniteVLSelfAttention":
@@ -191,6 +192,7 @@ class GatedDeltaNet(nn.Module):
         self._fused_w = None
         self._fused_cols = None
         self._gate32 = None
+        self.mma_dtype = None           # None = the reference's bf16 operands; "fp8_e4m3" = BASELINE.json configs[4]
 
     @torch.no_grad()
     def fuse_(self) -> "GatedDeltaNet":
@@ -263,9 +265,10 @@ class GatedDeltaNet(nn.Module):
             proj, (cq, ck, cv, ca, cb), (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight),
             prev, outs, A32, dt32, H, Dq, Dk, Dv)
         fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+        extra = {"mma_dtype": self.mma_dtype} if mode == "chunk" else {}
         o, _ = fn(q=q.view(B, T, H, K), k=k.view(B, T, self.num_key_value_heads, K), v=v.view(B, T, H, V), g=g,
                   beta=beta, initial_state=h0, use_qk_l2norm_in_kernel=True,
-                  final_state_out=layer.recurrent_state if layer is not None else None)
+                  final_state_out=layer.recurrent_state if layer is not None else None, **extra)
         if layer is not None:                                                          # std:1325-1333
             past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
                                    recurrent_state=layer.recurrent_state,
@@ -309,9 +312,10 @@ class GatedDeltaNet(nn.Module):
         g, beta = ops.gdn_gate(self.a_proj(hidden_states), self.b_proj(hidden_states), self.A_log, self.dt_bias)
 
         fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+        extra = {"mma_dtype": self.mma_dtype} if mode == "chunk" else {}
         o, next_state = fn(q=q, k=k, v=v, g=g, beta=beta, initial_state=recurrent_state,
                            output_final_state=use_cache and not native, use_qk_l2norm_in_kernel=True,
-                           final_state_out=layer.recurrent_state if native else None)
+                           final_state_out=layer.recurrent_state if native else None, **extra)
 
         if use_cache:                                                                  # std:1325-1333
             past_key_values.update(

@@ -19,9 +19,20 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import IVL_BF16, IVL_F32, SwaArgs
+from ._lib import IVL_BF16, IVL_F32, IVL_FP8_E4M3, SwaArgs
 
 _DT_CODE = {torch.bfloat16: IVL_BF16, torch.float32: IVL_F32}
+_MMA_CODE = {None: IVL_BF16, "bf16": IVL_BF16, torch.bfloat16: IVL_BF16, "fp8": IVL_FP8_E4M3, "fp8_e4m3": IVL_FP8_E4M3,
+             getattr(torch, "float8_e4m3fn", "fp8_e4m3"): IVL_FP8_E4M3}
+
+
+def mma_code(mma_dtype) -> int:
+    """Operand format of the MFMA products: None / "bf16" (the reference's precision) or "fp8_e4m3"
+    (BASELINE.json configs[4]: e4m3 operands, fp32 accumulation and state)."""
+    try:
+        return _MMA_CODE[mma_dtype]
+    except KeyError:
+        raise ValueError(f"mma_dtype must be None, 'bf16' or 'fp8_e4m3' (got {mma_dtype!r})") from None
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -155,9 +166,11 @@ def fused_recurrent_gated_delta_rule(
 def chunk_gated_delta_rule(
     q, k, v, g, beta, scale=None, initial_state=None, output_final_state=False, cu_seqlens=None,
     head_first=False, use_qk_l2norm_in_kernel=False, *, final_state_out: Optional[torch.Tensor] = None,
+    mma_dtype=None,
 ):
     """Chunkwise gated delta rule, chunk 64 (fla:ops/gated_delta_rule/chunk.py:272-392).  Same I/O
-    as fused_recurrent_gated_delta_rule; any T >= 1."""
+    as fused_recurrent_gated_delta_rule; any T >= 1.  `mma_dtype="fp8_e4m3"` (extension, configs[4]) runs the serial
+    pass's products on e4m3 operands."""
     if head_first:
         q, k, v, g, beta = _from_head_first(q, k, v, g, beta, cu_seqlens)
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
@@ -171,7 +184,7 @@ def chunk_gated_delta_rule(
         _p(q), _p(k), _p(v), _p(g), _p(beta), _p(o),
         _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
         _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
-        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _p(ws), ws.numel(), _stream(q)))
+        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), mma_code(mma_dtype), _p(ws), ws.numel(), _stream(q)))
     return (o.transpose(1, 2) if head_first else o), ht
 
 

@@ -75,7 +75,7 @@ def gdn_chunk(
     q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, g: torch.Tensor, beta: torch.Tensor,
     scale: Optional[float] = None, initial_state: Optional[torch.Tensor] = None,
     use_qk_l2norm_in_kernel: bool = True, chunk_size: int = 64,
-    rounding: Optional[torch.dtype] = None,
+    rounding: Optional[torch.dtype] = None, mma_rounding: Optional[torch.dtype] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Chunkwise form of the same rule (what the reference runs for T > 64).
 
@@ -94,11 +94,19 @@ def gdn_chunk(
     bf16 model (SURVEY.md section 8a'): q_hat,k_hat, beta*K, beta*V, Tw, Tu, w, u, v_new,
     the state snapshot and every dot operand rounded to bf16, fp32 accumulation,
     fp32 carried state and gamma.  `rounding=None` is exact fp32 math.
+
+    `mma_rounding=torch.float8_e4m3fn` models the build's fp8 variant (BASELINE.json configs[4]; the reference has no
+    such path): the operands of the serial pass's four products -- w e^gamma, q_hat, k_hat e^{gl-gamma}, A, the state
+    snapshot and v_new -- are rounded to OCP e4m3 (clamped to +-448) instead of bf16; everything else as `rounding` says.
     Returns (o [B,T,H,V] fp32, final_state [B,H,K,V] fp32).
     """
     B, T, H, K = q.shape
     V = v.shape[-1]
     C = chunk_size
+    if mma_rounding is None:
+        rdm = None
+    else:
+        rdm = lambda x: x.clamp(-448.0, 448.0).to(mma_rounding).float()  # noqa: E731
     if scale is None:
         scale = K ** -0.5
     if rounding is None:
@@ -147,12 +155,14 @@ def gdn_chunk(
         gc = gam[:, :, c]                                           # [B,H,C]
         last = min((c + 1) * C, T) - 1 - c * C
         g_last = gc[..., last]                                      # [B,H]
-        Sr = rd(S)
-        wg = rd(w[:, :, c] * gc.exp()[..., None])
-        v_new = rd(u[:, :, c] - wg @ Sr)
-        kd = rd(kc[:, :, c] * (g_last[..., None] - gc).exp()[..., None])
-        A = rd(torch.where(lower_incl, (qc[:, :, c] @ kc[:, :, c].transpose(-1, -2)) * Gamma[:, :, c], torch.zeros(())))
-        o[:, :, c] = ((qc[:, :, c] @ Sr) * gc.exp()[..., None]) * scale + (A @ v_new) * scale
+        ro = rd if rdm is None else rdm                             # rounding of the products' operands
+        Sr = ro(S)
+        wg = ro(w[:, :, c] * gc.exp()[..., None])
+        v_new = ro(u[:, :, c] - wg @ Sr)
+        kd = ro(kc[:, :, c] * (g_last[..., None] - gc).exp()[..., None])
+        A = ro(torch.where(lower_incl, (qc[:, :, c] @ kc[:, :, c].transpose(-1, -2)) * Gamma[:, :, c], torch.zeros(())))
+        qop = qc[:, :, c] if rdm is None else rdm(qc[:, :, c])
+        o[:, :, c] = ((qop @ Sr) * gc.exp()[..., None]) * scale + (A @ v_new) * scale
         S = S * g_last.exp()[..., None, None] + kd.transpose(-1, -2) @ v_new
     o = o.permute(0, 2, 3, 1, 4).reshape(B, NT * C, H, V)[:, :T]
     return o.contiguous(), S

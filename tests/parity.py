@@ -38,7 +38,7 @@ def gdn_inputs(seed: int, B: int, T: int, H: int, K: int = 128, V: int = 256, wi
 
 
 def gdn_op_parity(device: str, mode: str, B: int, T: int, H: int, seed: int = 0, with_h0: bool = True,
-                  state_dtype: torch.dtype = torch.float32, inplace_state: bool = False) -> Dict[str, float]:
+                  state_dtype: torch.dtype = torch.float32, inplace_state: bool = False, mma_dtype=None) -> Dict[str, float]:
     """HIP chunk / recurrent op vs the oracle.  Returns errors vs the exact fp32 oracle
     (`*_vs_exact`) and vs the oracle with the reference's bf16 rounding points (`*_vs_bf16model`)."""
     from infinitevl_amd import ops
@@ -50,6 +50,9 @@ def gdn_op_parity(device: str, mode: str, B: int, T: int, H: int, seed: int = 0,
     gd = g.to(dev)
     h0d = h0.to(dev, state_dtype) if h0 is not None else None
     fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+    if mma_dtype is not None:
+        import functools
+        fn = functools.partial(fn, mma_dtype=mma_dtype)
     if inplace_state:
         out_state = h0d if h0d is not None else torch.zeros(B, H, 128, 256, dtype=state_dtype, device=dev)
         o, ht = fn(qd, kd, vd, gd, bd, initial_state=h0d, use_qk_l2norm_in_kernel=True, final_state_out=out_state)
@@ -65,6 +68,10 @@ def gdn_op_parity(device: str, mode: str, B: int, T: int, H: int, seed: int = 0,
         o_bf, s_bf = ogdn.gdn_recurrent(q, k, v, g, beta, initial_state=h0, qk_round_dtype=torch.bfloat16)
     res["o_vs_bf16model"] = rms_rel(o_bf.to(torch.bfloat16).float(), o.float())
     res["s_vs_bf16model"] = rms_rel(s_bf, ht.float())
+    if mma_dtype is not None and mode == "chunk":
+        o_f8, s_f8 = ogdn.gdn_chunk(q, k, v, g, beta, initial_state=h0, rounding=torch.bfloat16, mma_rounding=torch.float8_e4m3fn)
+        res["o_vs_fp8model"] = rms_rel(o_f8.to(torch.bfloat16).float(), o.float())
+        res["s_vs_fp8model"] = rms_rel(s_f8, ht.float())
     res["finite"] = float(torch.isfinite(o.float()).all() and torch.isfinite(ht.float()).all())
     return res
 

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivl_abi_version() == 1
+    assert lib.ivl_abi_version() == 2
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
@@ -62,8 +62,10 @@ def test_argument_validation_returns_codes(lib):
     assert lib.ivl_short_conv_fwd(one, one, None, one, None, 0, 1, 8, 4, 1, None) == _lib.IVL_ERR_INVALID_ARG
     assert lib.ivl_gdn_recurrent_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 1, 2, 64, 256, 1.0, 1, None) \
         == _lib.IVL_ERR_UNSUPPORTED                                        # K != 128
-    assert lib.ivl_gdn_chunk_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 100, 2, 128, 256, 1.0, 1,
+    assert lib.ivl_gdn_chunk_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 100, 2, 128, 256, 1.0, 1, 0,
                                  one, 16, None) == _lib.IVL_ERR_WORKSPACE
+    assert lib.ivl_gdn_chunk_fwd(one, one, one, one, one, one, None, 2, None, 2, 1, 100, 2, 128, 256, 1.0, 1, 1,
+                                 one, 1 << 30, None) == _lib.IVL_ERR_INVALID_ARG                  # mma_dtype: bf16 or e4m3 only
     assert lib.ivl_rmsnorm_swish_gate_fwd(one, one, one, one, 4, 128, 1e-5, None) == _lib.IVL_ERR_UNSUPPORTED
     assert lib.ivl_mrope_fwd(one, one, one, one, 1, 1, 2, 1, 128, 16, 24, 23, None) == _lib.IVL_ERR_UNSUPPORTED
     assert lib.ivl_swa_fwd(None, None) == _lib.IVL_ERR_INVALID_ARG
