@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the 4K one-call prefill + decode leg (configs[1])")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (e4m3) leg (BASELINE.json configs[4])")
     return ap.parse_args()
 
 
@@ -386,6 +387,42 @@ def main():
     dec_elapsed = ivd.max_over_ranks(time.perf_counter() - t1, device)
     mem_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
+    # ---- fp8 leg (rank 0, reported beside the headline, never mixed into `value`): BASELINE.json configs[4] -- the same
+    #      steady-state streaming step and decode step with e4m3 operands in the GDN chunk scan / SWA decode step
+    fp8 = None
+    if rank == 0 and not args.no_fp8:
+        model.set_mma_dtype("fp8_e4m3")
+        cache8 = cache.clone()
+        step8 = GraphedStep(model, cache8, B_local, T, logits_to_keep=1)
+        step8.capture()
+        for i in range(4):
+            step8.step(frames[i % 4])
+        torch.cuda.synchronize()
+        tA = time.perf_counter()
+        n8 = 32
+        for i in range(n8):
+            step8.step(frames[i % 4])
+        torch.cuda.synchronize()
+        t8 = (time.perf_counter() - tA) / n8
+        fin8 = bool(torch.isfinite(step8.logits.float()).all())
+        dec8 = GraphedDecode(model, cache8, B_local)
+        dec8.token.copy_(step8.logits[:, -1].argmax(-1, keepdim=True))
+        dec8.capture()
+        for _ in range(4):
+            dec8.step()
+        torch.cuda.synchronize()
+        tA = time.perf_counter()
+        for _ in range(n8):
+            dec8.step()
+        torch.cuda.synchronize()
+        td8 = (time.perf_counter() - tA) / n8
+        fp8 = {"workload": "the same steady-state 256-token streaming step and decode step with e4m3 operands in the GDN chunk "
+                           "scan and the SWA decode products (fp32 accumulation and state)", "steps_timed": n8,
+               "ms_per_step": t8 * 1e3, "prefill_tok_s": T / t8, "decode_ms_per_token": td8 * 1e3, "decode_tok_s": 1.0 / td8,
+               "frames_per_s_at_256_tokens": 1.0 / t8, "frame_budget_ms_24fps": 1000.0 / 24, "logits_finite": fin8}
+        model.set_mma_dtype(None)
+        del step8, dec8, cache8
+
     # ---- configs[1] leg (rank 0, N=1; reported beside the headline, never mixed into `value`): one 4096-token
     #      prefill call on a fresh cache (chunk path over 64 chunks; SWA purely causal) + 128 graphed decode steps
     cfg1 = None
@@ -465,6 +502,8 @@ def main():
             out["hot_path_ms_per_step"] = sum(step_ms(v) for v in prefill_kernels.values())
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if fp8 is not None:
+            out["fp8_e4m3"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in fp8.items()}
         if cfg1 is not None:
             out["cfg1_4k_prefill_decode"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg1.items()}
         print(json.dumps(out))

@@ -155,6 +155,9 @@ typedef struct ivl_swa_args {
   float scaling;
   void* workspace;
   size_t workspace_bytes;
+  int mma_dtype;            /* IVL_BF16 (the reference's precision) or IVL_FP8_E4M3: the single-token decode step
+                               (T * Hq/Hkv <= 64 packed rows) rounds q, K, V and the probabilities to e4m3 for the two
+                               products (BASELINE.json configs[4]); longer calls always run in bf16                  */
 } ivl_swa_args;
 
 IVL_API size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);

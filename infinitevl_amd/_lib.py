@@ -39,6 +39,7 @@ class SwaArgs(Structure):
         ("pos", c_int64), ("pos_dev", c_void_p),
         ("scaling", c_float),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("mma_dtype", c_int),
     ]
 
 

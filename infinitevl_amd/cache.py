@@ -102,7 +102,7 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         return self.keys, self.values
 
     def attend(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, scaling: float,
-               window: Optional[int]) -> torch.Tensor:
+               window: Optional[int], mma_dtype=None) -> torch.Tensor:
         """q [B,T,Hq,d], k_new/v_new [B,T,Hkv,d] (time-major, post-RoPE).  Attention over
         (ring ++ new) with the band of SURVEY.md section 8a S2, then append + advance.  Returns [B,T,Hq,d]."""
         B, T, Hkv, D = k_new.shape
@@ -111,7 +111,7 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         if Hkv != self.num_kv_heads or D != self.head_dim:
             raise ValueError(f"SWA head dim mismatch: got H={Hkv},D={D}, expect H={self.num_kv_heads},D={self.head_dim}")
         o = ops.swa_forward(q, k_new, v_new, window=window, scaling=scaling,
-                            k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev)
+                            k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev, mma_dtype=mma_dtype)
         if self.capacity > 0:
             ops.swa_cache_append(k_new, v_new, self._buf_keys, self._buf_values, pos_dev=self._pos_dev)
         ops.counter_add(self._pos_dev, T)

@@ -789,23 +789,24 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
       sb[s] = to_frag<F8>(S[2 * s], S[2 * s + 1]);
       *(frag_t*)(xsb + s * BLK + lanef) = sb[s];
     }
+    // work that needs nothing from the other waves sits between the publish and the barrier: it covers the LDS-write drain
+    f32x4 accV[4];                       // u (bf16) is the C input of v_new = u + Wn S
+#pragma unroll
+    for (int m = 0; m < 4; ++m) accV[m] = f32x4{bflo(uu[m].x), bfhi(uu[m].x), bflo(uu[m].y), bfhi(uu[m].y)};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) S[t] *= egl;
     IVL_T(tc_a);
     lds_barrier();                       // T(ci): H2 of this chunk has landed
     IVL_T(tc_b);
     frag_t fk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) fk[i] = frag(img, R::KDT, i);              // land under the 16 MFMAs below
-    // ---- v_new = u + Wn S   (time tiles m, lane (g, j) register r <-> time 16m + 4g + r, column j); u (bf16) is the C input
-    f32x4 accV[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) accV[m] = f32x4{bflo(uu[m].x), bfhi(uu[m].x), bflo(uu[m].y), bfhi(uu[m].y)};
+    // ---- v_new = u + Wn S   (time tiles m, lane (g, j) register r <-> time 16m + 4g + r, column j) -------------------------
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
         accV[m] = mma16<F8>(fw[4 * m + s], sb[s], accV[m]);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) S[t] *= egl;
     frag_t vn[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {

@@ -380,6 +380,191 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp8 (e4m3) variant of the packed DECODE step (BASELINE.json configs[4]; the reference has no such path): q, the K / V
+// tile and the probabilities are rounded to OCP e4m3 and both products run on v_mfma_f32_16x16x32_fp8_fp8; scores, the
+// online softmax, the row sums and the output accumulators stay fp32.  Same band, same split-KV partials and combine
+// kernels as the bf16 path.  The ring cache stays bf16 in HBM (the tile is converted while it is staged): the variant
+// halves the LDS traffic per MFMA, not the HBM read.
+//   K image : [64 keys][128 B], row stride 136 B           A fragment of S^T = K Q^T: 8 bytes at d = 32 ks + 8 g
+//   V^T image: [128 d][64 B], row stride 72 B, key 32 ks2 + r stored at byte 32 ks2 + (r < 16 ? 8 (r >> 2) + (r & 3)
+//             : 8 ((r - 16) >> 2) + 4 + (r & 3))  = the slot order of the probabilities in the accumulators
+constexpr int F8_KSTRIDE = 136, F8_VSTRIDE = 72;
+constexpr int F8_LDS_K = SWA_KT * F8_KSTRIDE;
+constexpr int F8_LDS_BYTES = F8_LDS_K + SWA_D * F8_VSTRIDE;
+
+__device__ __forceinline__ unsigned int pack4_fp8(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned int)r;
+}
+__device__ __forceinline__ u32x2 bf16x8_to_fp8(u32x4 v) {
+  return u32x2{pack4_fp8(bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y)), pack4_fp8(bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w))};
+}
+__device__ __forceinline__ f32x4 mma_fp8(u32x2 a, u32x2 b, f32x4 c) {
+  long la, lb;
+  __builtin_memcpy(&la, &a, 8);
+  __builtin_memcpy(&lb, &b, 8);
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[F8_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int G = p.Hq / p.Hkv;
+  // grid = B * nsplit * Hkv (one 64-row packed query tile per kv head); ordered (b, split, kv head)
+  const int hk = blockIdx.x % p.Hkv;
+  const int bz = blockIdx.x / p.Hkv;
+  const int b = bz / p.nsplit, split = bz % p.nsplit;
+
+  const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
+  const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
+  const int n_extra = p.T_new - p.T;
+  const int n_prev = n_ring + n_extra;
+  const int S = n_prev + p.T;
+  const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;
+
+  const int total_rows = p.T * G;
+  const int row = wave * 16 + l15;
+  const bool row_ok = row < total_rows;
+  const int t_row = row / G, hq = hk * G + row % G;
+  const int hi = n_prev + t_row;
+  const int lo = p.W > 0 ? max(0, n_prev + t_row - p.W + 1) : 0;
+
+  const int t_max = (total_rows - 1) / G;
+  const int lo_min = p.W > 0 ? max(0, n_prev - p.W + 1) : 0;
+  const int kt0 = lo_min / SWA_KT, kt1 = (n_prev + t_max) / SWA_KT + 1;
+  const int per = (kt1 - kt0 + p.nsplit - 1) / p.nsplit;
+  const int kt_begin = kt0 + split * per;
+  const int kt_end = min(kt1, kt_begin + per);
+
+  // Q fragments in e4m3: lane = query row, k-slots 8g..8g+7 of each 32-chunk
+  u32x2 qf[4];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)t_row * p.q_st + (long long)hq * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_ok ? bf16x8_to_fp8(*(const u32x4*)(qp + 32 * ks + 8 * g)) : u32x2{0u, 0u};
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 oacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 4, schunk = tid & 15;
+  const bf16_t* kb_ring = p.C > 0 ? p.k_cache + (((long long)b * p.Hkv + hk) * p.C) * SWA_D + schunk * 8 : p.k_new;
+  const bf16_t* vb_ring = p.C > 0 ? p.v_cache + (((long long)b * p.Hkv + hk) * p.C) * SWA_D + schunk * 8 : p.v_new;
+  const bf16_t* kb_new = p.k_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
+  const bf16_t* vb_new = p.v_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
+  const unsigned int kn_st32 = (unsigned int)p.kn_st;
+  const float sc = p.scaling * LOG2E;
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int j0 = kt * SWA_KT;
+    // ---- stage the tile: branch-free clamped loads (ring wrap / seam / tail), converted to e4m3 on the way to LDS ----
+    u32x4 kreg[4], vreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + srow + 16 * i;
+      const int jc = min(j, S - 1);
+      const bool in_ring = jc < n_ring;
+      int slot = s0 + jc;
+      slot = slot >= p.C ? slot - p.C : slot;
+      const unsigned int off = in_ring ? (unsigned int)slot * SWA_D : (unsigned int)(jc - n_ring) * kn_st32;
+      kreg[i] = *(const u32x4*)((in_ring ? kb_ring : kb_new) + off);
+      vreg[i] = *(const u32x4*)((in_ring ? vb_ring : vb_new) + off);
+      if (j >= S) { kreg[i] = u32x4{0u, 0u, 0u, 0u}; vreg[i] = u32x4{0u, 0u, 0u, 0u}; }
+    }
+    __syncthreads();                     // the previous tile's readers are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 16 * i;       // key within the tile
+      *(u32x2*)(smem + r * F8_KSTRIDE + schunk * 8) = bf16x8_to_fp8(kreg[i]);
+      const u32x2 v8 = bf16x8_to_fp8(vreg[i]);
+      const int r32 = r & 31;
+      const int kpos = (r & 32) + (r32 < 16 ? 8 * (r32 >> 2) + (r32 & 3) : 8 * ((r32 - 16) >> 2) + 4 + (r32 & 3));
+      unsigned char* vt = smem + F8_LDS_K + (schunk * 8) * F8_VSTRIDE + kpos;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vt[c * F8_VSTRIDE] = (unsigned char)((c < 4 ? v8.x >> (8 * c) : v8.y >> (8 * (c - 4))) & 0xffu);
+    }
+    __syncthreads();
+    // ---- S^T = K Q^T ----------------------------------------------------------------------------------------------
+    f32x4 sacc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        sacc[mt] = mma_fp8(*(const u32x2*)(smem + (16 * mt + l15) * F8_KSTRIDE + 32 * ks + 8 * g), qf[ks], sacc[mt]);
+    // ---- band + online softmax (lane-local row) -------------------------------------------------------------------
+    const int jbase = j0 + 4 * g;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jbase + 16 * mt + r;
+        sacc[mt][r] = (row_ok && j >= lo && j <= hi) ? sacc[mt][r] : -INFINITY;
+      }
+    float rmax = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rmax = vmax2(rmax, sacc[mt][r]);
+    rmax = group_max(rmax) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    float rsum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][r], sc, -m_use));
+        sacc[mt][r] = pv;
+        rsum += pv;
+      }
+    rsum = group_sum(rsum);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    l_run = l_run * alpha + rsum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oacc[i] *= alpha;
+    m_run = m_new;
+    u32x2 pf[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+      pf[ks2] = u32x2{pack4_fp8(sacc[2 * ks2][0], sacc[2 * ks2][1], sacc[2 * ks2][2], sacc[2 * ks2][3]),
+                      pack4_fp8(sacc[2 * ks2 + 1][0], sacc[2 * ks2 + 1][1], sacc[2 * ks2 + 1][2], sacc[2 * ks2 + 1][3])};
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2)
+        oacc[mt2] = mma_fp8(*(const u32x2*)(smem + F8_LDS_K + (16 * mt2 + l15) * F8_VSTRIDE + 32 * ks2 + 8 * g), pf[ks2], oacc[mt2]);
+  }
+
+  if (!row_ok) return;
+  if (p.nsplit == 1) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* op = p.o + (((long long)b * p.T + t_row) * p.Hq + hq) * SWA_D + 4 * g;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2)
+      *(u32x2*)(op + 16 * mt2) = u32x2{pack2bf(oacc[mt2][0] * inv, oacc[mt2][1] * inv), pack2bf(oacc[mt2][2] * inv, oacc[mt2][3] * inv)};
+  } else {
+    const long long prow = (((long long)b * p.nsplit + split) * p.T + t_row) * p.Hq + hq;
+    float* po = p.part_o + prow * SWA_D + 4 * g;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 8; ++mt2) *(f32x4*)(po + 16 * mt2) = oacc[mt2];
+    if (g == 0) {
+      p.part_ml[prow * 2] = m_run;
+      p.part_ml[prow * 2 + 1] = l_run;
+    }
+  }
+}
+
 // merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane; every split's loads are
 // issued before the first use (template on the split count so the loop is fully unrolled)
 template <int NS>
@@ -514,6 +699,8 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   IVL_REQUIRE(a->cache_capacity >= 0 && (a->cache_capacity == 0 || (a->k_cache && a->v_cache)), IVL_ERR_INVALID_ARG,
               "ivl_swa_fwd: cache_capacity=%d needs k_cache/v_cache", a->cache_capacity);
   IVL_REQUIRE(a->pos_dev != nullptr || a->pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: negative pos");
+  IVL_REQUIRE(a->mma_dtype == IVL_BF16 || a->mma_dtype == IVL_FP8_E4M3, IVL_ERR_INVALID_ARG,
+              "ivl_swa_fwd: mma_dtype must be IVL_BF16 or IVL_FP8_E4M3 (got %d)", a->mma_dtype);
   // new-key rows are addressed with 32-bit element offsets from the (batch, kv-head) base
   IVL_REQUIRE((long long)a->T_new * a->kn_st < (1LL << 32) && a->kn_st >= 0, IVL_ERR_UNSUPPORTED,
               "ivl_swa_fwd: T_new * kn_st = %lld elements exceeds the 32-bit row addressing of the kernel (split the call)",
@@ -556,7 +743,9 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.n_qtiles = (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);
+  if (pack && a->mma_dtype == IVL_FP8_E4M3)
+    hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
+  else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);
   else if (qg == 2) hipLaunchKernelGGL((swa_fwd_kernel<false, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p);
   int rc = check_launch("ivl_swa_fwd");

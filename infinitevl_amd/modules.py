@@ -120,7 +120,7 @@ class InfiniteVLSelfAttention(nn.Module):
 
         layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
         if isinstance(layer, StaticSlidingWindowLayerPrealloc):
-            attn = layer.attend(q, k, v, self.scaling, self.sliding_window)               # std:1067-1108 fused
+            attn = layer.attend(q, k, v, self.scaling, self.sliding_window, mma_dtype=self.mma_dtype)   # std:1067-1108 fused
         elif layer is None:
             attn = ops.swa_forward(q, k, v, window=self.sliding_window, scaling=self.scaling)
         else:  # foreign cache object: go through the reference protocol (cat of cached + new)

@@ -449,7 +449,7 @@ def swa_forward(
     q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, *, window: Optional[int], scaling: float,
     k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
     pos: int = 0, pos_dev: Optional[torch.Tensor] = None, n_query: Optional[int] = None,
-    layout: str = "bthd",
+    layout: str = "bthd", mma_dtype=None,
 ) -> torch.Tensor:
     """Sliding-window GQA attention over (ring cache ++ new keys); returns o [B,T,Hq,d] bf16.
 
@@ -491,6 +491,7 @@ def swa_forward(
     a.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
     a.scaling = float(scaling)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    a.mma_dtype = mma_code(mma_dtype)
     _lib.check(lib.ivl_swa_fwd(ctypes.byref(a), _stream(q)))
     return o
 

@@ -53,13 +53,16 @@ def band_mask(n_prev: int, T: int, window: int) -> np.ndarray:
 def swa_attention(
     q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_prev: int, window: int,
     scaling: Optional[float] = None, p_round_dtype: Optional[torch.dtype] = None,
+    mma_rounding: Optional[torch.dtype] = None,
 ) -> torch.Tensor:
     """softmax_fp32(q k^T * scaling + band) v with GQA; the math of std:557-580.
 
     q [B,Hq,T,d]; k,v [B,Hkv,S,d] with S = n_prev + T (cached keys first).
     Returns [B,T,Hq,d] fp32 (the layout attention_interface returns, std:578).
     `p_round_dtype` reproduces that the probabilities are cast to the activation
-    dtype before P@V (std:575).
+    dtype before P@V (std:575).  `mma_rounding=torch.float8_e4m3fn` models the operand rounding of the build's fp8
+    decode variant (BASELINE.json configs[4]; no counterpart in the reference): q, k and v are rounded to OCP e4m3
+    before the two products (the probabilities are left exact: their e4m3 rounding depends on the tiling of the kernel).
     """
     B, Hq, T, d = q.shape
     Hkv, S = k.shape[1], k.shape[2]
@@ -67,9 +70,10 @@ def swa_attention(
     if scaling is None:
         scaling = d ** -0.5
     rep = Hq // Hkv
-    kf = k.float().repeat_interleave(rep, dim=1)
-    vf = v.float().repeat_interleave(rep, dim=1)
-    scores = torch.matmul(q.float(), kf.transpose(2, 3)) * scaling
+    r8 = (lambda x: x) if mma_rounding is None else (lambda x: x.clamp(-448.0, 448.0).to(mma_rounding).float())
+    kf = r8(k.float()).repeat_interleave(rep, dim=1)
+    vf = r8(v.float()).repeat_interleave(rep, dim=1)
+    scores = torch.matmul(r8(q.float()), kf.transpose(2, 3)) * scaling
     mask = torch.from_numpy(band_mask(n_prev, T, window))
     scores = scores.masked_fill(~mask[None, None], float("-inf"))
     p = torch.softmax(scores, dim=-1, dtype=torch.float32)

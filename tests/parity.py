@@ -77,7 +77,7 @@ def gdn_op_parity(device: str, mode: str, B: int, T: int, H: int, seed: int = 0,
 
 
 def swa_op_parity(device: str, B: int, T: int, Hq: int, Hkv: int, window: int, seen: int, seed: int = 0,
-                  via: str = "ring", d: int = 128) -> Dict[str, float]:
+                  via: str = "ring", d: int = 128, mma_dtype=None) -> Dict[str, float]:
     """HIP SWA vs oracle.  `seen` tokens precede the call.  via="ring": the previous keys are fed
     through the ring-buffer cache (filled by earlier appends); via="cat": operator-level call with the
     concatenated K/V (swa_attention_interface)."""
@@ -112,10 +112,17 @@ def swa_op_parity(device: str, B: int, T: int, Hq: int, Hkv: int, window: int, s
             pos += n
             step = step * 2 + 1
         out = ops.swa_forward(qd, kd[:, seen:], vd[:, seen:], window=window, scaling=d ** -0.5,
-                              k_cache=kc, v_cache=vc, pos_dev=pos_dev)
+                              k_cache=kc, v_cache=vc, pos_dev=pos_dev, mma_dtype=mma_dtype)
     torch.cuda.synchronize()
-    return {"o": rms_rel(ref, out.float()), "max_abs": max_abs(ref, out.float()),
-            "finite": float(torch.isfinite(out.float()).all())}
+    res = {"o": rms_rel(ref, out.float()), "max_abs": max_abs(ref, out.float()),
+           "finite": float(torch.isfinite(out.float()).all())}
+    if mma_dtype is not None:
+        ref8 = oswa.swa_attention(q.transpose(1, 2), k_all[:, seen - n_prev:].transpose(1, 2),
+                                  v_all[:, seen - n_prev:].transpose(1, 2), n_prev, window, d ** -0.5,
+                                  mma_rounding=torch.float8_e4m3fn)
+        res["o_vs_fp8model"] = rms_rel(ref8, out.float())
+        res["fp8model_vs_exact"] = rms_rel(ref, ref8)
+    return res
 
 
 # ---------------------------------------------------------------------------------------------

@@ -88,8 +88,9 @@ def test_gdn_vs_oracle(mode, B, T, H, h0, sd, inplace):
 # fp8 (e4m3) operand variant of the chunk rule -- BASELINE.json configs[4].  The reference has no fp8 path, so the
 # tolerance is the build's own statement: e4m3 carries 3 mantissa bits (relative rounding error <= 2^-4 per operand),
 # which puts the oracle WITH the same fp8 rounding points at 3.9e-2 RMS-relative from the exact fp32 result on this input
-# distribution.  The HIP path must (a) reproduce that fp8-rounding model within 1.5e-2 (what remains is e4m3 rounding
-# flips caused by fp32 summation order) and (b) stay within 8e-2 of the exact result -- 2x the model's own distance.
+# distribution.  The HIP path must (a) reproduce that fp8-rounding model within 1e-3 (observed 6e-5 .. 9e-5: what remains
+# is e4m3 rounding flips caused by fp32 summation order) and (b) stay within 8e-2 of the exact result -- 2x the model's own
+# distance.
 @pytest.mark.parametrize("B,T,H,h0,sd,inplace", [
     (1, 65, 2, True, torch.float32, False), (1, 256, 16, True, torch.bfloat16, True), (2, 300, 3, False, torch.float32, False),
     (1, 1000, 2, True, torch.float32, False),
@@ -98,7 +99,7 @@ def test_gdn_fp8_vs_oracle(B, T, H, h0, sd, inplace):
     r = parity.gdn_op_parity(DEV, "chunk", B, T, H, seed=T + H, with_h0=h0, state_dtype=sd, inplace_state=inplace,
                              mma_dtype="fp8_e4m3")
     assert r["finite"] == 1.0
-    assert r["o_vs_fp8model"] < 1.5e-2 and r["s_vs_fp8model"] < 1.5e-2, r
+    assert r["o_vs_fp8model"] < 1e-3 and r["s_vs_fp8model"] < 1e-3, r
     assert r["o_vs_exact"] < 8e-2 and r["s_vs_exact"] < 8e-2, r
     assert r["o_vs_exact"] > 5e-3, ("the fp8 variant should not be as accurate as the bf16 one", r)
 
@@ -272,6 +273,26 @@ SWA_CASES = [
 def test_swa_vs_oracle(B, T, Hq, Hkv, W, seen, via):
     r = parity.swa_op_parity(DEV, B, T, Hq, Hkv, W, seen, seed=T + seen, via=via)
     assert r["finite"] == 1.0 and r["o"] < 5e-3, r
+
+
+# fp8 (e4m3) decode step -- BASELINE.json configs[4]; the build's own tolerance (the reference has no fp8 path): with q, K,
+# V rounded to e4m3 (3 mantissa bits) the oracle sits ~3e-2 RMS-relative from the exact result; the kernel additionally
+# rounds the probabilities to e4m3 (relative 2^-4 each, averaged over >= 64 keys per tile), so it must stay within 3e-2 of
+# that operand-rounding model (bound 4e-2, observed 2e-2) and within 8e-2 of the exact fp32 result (observed 5e-2, the
+# operand-rounding model itself 4.6e-2).  Calls longer than the packed decode tile run bf16.
+@pytest.mark.parametrize("B,T,Hq,Hkv,W,seen", [(1, 1, 16, 2, 4096, 5000), (2, 1, 16, 2, 96, 40), (1, 4, 16, 2, 4096, 6000),
+                                                (1, 1, 16, 2, 4096, 100), (1, 8, 16, 2, 2048, 1500), (1, 1, 16, 2, 2, 5)])
+def test_swa_fp8_decode_vs_oracle(B, T, Hq, Hkv, W, seen):
+    r = parity.swa_op_parity(DEV, B, T, Hq, Hkv, W, seen, seed=T + seen, via="ring", mma_dtype="fp8_e4m3")
+    assert r["finite"] == 1.0
+    assert r["o_vs_fp8model"] < 4e-2 and r["o"] < 8e-2, r
+    if W > 2:
+        assert r["o"] > 5e-3, ("the fp8 variant should not be as accurate as the bf16 one", r)
+
+
+def test_swa_fp8_prefill_calls_stay_bf16():
+    r = parity.swa_op_parity(DEV, 1, 70, 2, 1, 96, 250, seed=1, via="ring", mma_dtype="fp8_e4m3")
+    assert r["o"] < 5e-3, r
 
 
 def _band_counts(n_prev, T, W):
@@ -676,6 +697,78 @@ def test_full_size_model_streams_512k_tokens_in_constant_memory():
         assert int(cache.layers[0]._pos_dev.item()) == 524288 and cache.layers[0].size == 4095
         assert torch.isfinite(gs.hidden.float()).all() and torch.isfinite(gs.logits.float()).all()
         assert cache.memory_bytes() < 80 * 2 ** 20          # 27 MiB GDN state + 1.7 MiB conv + 37.7 MB SWA ring
+    del model, gs, cache
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_full_size_model_streams_1m_tokens_in_fp8():
+    """BASELINE.json configs[4]: "fp8 MFMA Gated DeltaNet + SWA decode, continuous 1M-token stream, 1 MI355X".  The real
+    InfiniteVL-3B decoder shape, e4m3 operands in the GDN chunk scan (every 256-token frame) and in the SWA decode step,
+    4096 hipGraph steps x 256 tokens = 1,048,576 tokens with a greedy decode burst every 512 frames (as the demo answers
+    questions during a stream, on a cloned cache): allocated memory flat once the window is full, finite activations to
+    the end, step time inside the 24 FPS frame budget (41.7 ms), and the first frames within 0.25 RMS-relative of the
+    bf16 model's hidden states (random-init weights: 36 layers amplify the 4 % operand noise of e4m3)."""
+    import gc
+    import time
+    from infinitevl_amd.harness import GraphedDecode, GraphedStep, InfiniteVLTextConfig, InfiniteVLTextStack
+    cfg = InfiniteVLTextConfig(sliding_window=4096)
+    with torch.device(DEV):
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            model = InfiniteVLTextStack(cfg)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    model = model.to(torch.bfloat16).eval()
+    model.init_weights_(seed=0).fuse_()
+    T = 256
+    g_ = torch.Generator(device=DEV).manual_seed(11)
+    frames = [(torch.randn(1, T, cfg.hidden_size, device=DEV, generator=g_) * 0.02).to(torch.bfloat16) for _ in range(3)]
+    with torch.no_grad():
+        # bf16 reference for the first frames (eager)
+        cb = model.allocate_inference_cache(1)
+        ref = []
+        for i in range(3):
+            pid = torch.arange(i * T, (i + 1) * T, device=DEV)[None, None, :].expand(3, 1, T)
+            ref.append(model(inputs_embeds=frames[i], position_ids=pid, past_key_values=cb)[0].float().clone())
+        del cb
+        model.set_mma_dtype("fp8_e4m3")
+        cache = model.allocate_inference_cache(1)
+        gs = GraphedStep(model, cache, 1, T, logits_to_keep=1)
+        for i in range(3):
+            h, _ = gs.step(frames[i])
+            e = parity.rms_rel(ref[i], h.float())
+            assert 1e-3 < e < 0.25, (i, e)
+        for i in range(3, 20):
+            gs.step(frames[i % 3])
+        torch.cuda.synchronize()
+        gc.collect()
+        base = torch.cuda.memory_allocated()
+        dec = None
+        t0 = time.perf_counter()
+        for i in range(20, 4096):
+            gs.step(frames[i % 3])
+            if i % 512 == 0:                         # answer a question mid-stream: decode on a clone (fp8 SWA decode step)
+                torch.cuda.synchronize()
+                branch = cache.clone()
+                dec = GraphedDecode(model, branch, 1)
+                dec.token.copy_(gs.logits[:, -1].argmax(-1, keepdim=True))
+                for _ in range(8):
+                    dec.step()
+                torch.cuda.synchronize()
+                assert torch.isfinite(dec.logits.float()).all()
+                del dec, branch
+                gc.collect()
+                torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        gc.collect()
+        assert torch.cuda.memory_allocated() <= base, (torch.cuda.memory_allocated(), base)
+        assert cache.get_seq_length() == 4096 * 256 == 1048576
+        assert int(cache.layers[0]._pos_dev.item()) == 1048576
+        assert torch.isfinite(gs.hidden.float()).all() and torch.isfinite(gs.logits.float()).all()
+        assert wall / (4096 - 20) < 41.7e-3, wall
+    model.set_mma_dtype(None)
     del model, gs, cache
     gc.collect()
     torch.cuda.empty_cache()
