@@ -99,7 +99,7 @@ def test_gdn_fp8_vs_oracle(B, T, H, h0, sd, inplace):
     r = parity.gdn_op_parity(DEV, "chunk", B, T, H, seed=T + H, with_h0=h0, state_dtype=sd, inplace_state=inplace,
                              mma_dtype="fp8_e4m3")
     assert r["finite"] == 1.0
-    assert r["o_vs_fp8model"] < 1e-3 and r["s_vs_fp8model"] < 1e-3, r
+    assert r["o_vs_fp8model"] < 1e-3 and r["s_vs_fp8model"] < (3e-3 if sd == torch.bfloat16 else 1e-3), r   # bf16-stored state: 2^-9
     assert r["o_vs_exact"] < 8e-2 and r["s_vs_exact"] < 8e-2, r
     assert r["o_vs_exact"] > 5e-3, ("the fp8 variant should not be as accurate as the bf16 one", r)
 
