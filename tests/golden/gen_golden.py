@@ -261,6 +261,23 @@ def gen_cache_traces(ns):
         pos += T
     out["W8_tail_positions"] = np.concatenate(tails)
     out["W8_tail_lengths"] = np.array([len(t) for t in tails])
+    # crop (std:192-213): ops = +n: update with n tokens, c: crop(c) encoded as 1000 + c (c may be negative)
+    cfg = tiny_cfg(["sliding_attention"], W=8)
+    layer = std.StaticSlidingWindowLayerPrealloc(config=cfg, batch_size=1, dtype=torch.float32)
+    ops_, tails, ctr, pos = [3, 1000 + 2, 2, 1000 - 1, 1, 1000 + 9, 2], [], [], 0
+    for op in ops_:
+        if op < 500:
+            k = torch.arange(pos, pos + op, dtype=torch.float32)[None, None, :, None].expand(1, 2, op, 16).contiguous()
+            layer.update(k, -k)
+            pos += op
+        else:
+            layer.crop(op - 1000)
+        tails.append(layer.keys[0, 0, :, 0].clone().numpy())
+        ctr.append((layer.size, layer.cumulative_length))
+    out["crop_ops"] = np.array(ops_)
+    out["crop_tail_positions"] = np.concatenate(tails)
+    out["crop_tail_lengths"] = np.array([len(t) for t in tails])
+    out["crop_counters"] = np.array(ctr, dtype=np.int64)
     save("cache_traces", **out)
 
 
@@ -389,13 +406,148 @@ def gen_layers(ns):
     save("tiny_mixers", x_gdn=x, o_gdn=o_gdn, x_swa=xs, pos3=pos3.numpy(), o_swa=o_swa)
 
 
+def gen_swa_d128(ns):
+    """The reference's eager attention at the head shape the HIP kernel is built for (d = 128, GQA group 8 as in the
+    model, 16/2 heads once), band mask from the S2 predicate, W smaller and larger than T: consumed DIRECTLY by the GPU
+    tests (tests/test_gpu_parity.py::test_swa_reference_vectors_d128)."""
+    print("[swa_d128] eager_attention_forward at d=128")
+    std = ns.std
+    torch.manual_seed(12)
+    att, names = {}, []
+    for name, Hq, Hkv, W, n_prev, T in (("empty_Tlt", 8, 1, 96, 0, 40), ("empty_Tgt", 8, 1, 96, 0, 130),
+                                        ("cached_full", 8, 1, 96, 95, 70), ("decode", 8, 1, 96, 95, 1),
+                                        ("cached_part", 8, 1, 96, 30, 60), ("gqa16x2_full", 16, 2, 64, 63, 33),
+                                        ("wide_window", 8, 1, 4096, 100, 29)):
+        class _M:
+            num_key_value_groups = Hq // Hkv
+            training = False
+        q = snap(torch.randn(1, Hq, T, 128))
+        k = snap(torch.randn(1, Hkv, n_prev + T, 128))
+        v = snap(torch.randn(1, Hkv, n_prev + T, 128))
+        i = torch.arange(T)[:, None] + n_prev
+        j = torch.arange(n_prev + T)[None, :]
+        vis = (j <= i) & (j > i - W)
+        mask = torch.zeros(T, n_prev + T).masked_fill(~vis, float("-inf"))[None, None]
+        out, _ = std.eager_attention_forward(_M(), q, k, v, mask, scaling=128 ** -0.5)
+        names.append(name)
+        att.update({f"{name}_q_bf16bits": bits(q), f"{name}_k_bf16bits": bits(k), f"{name}_v_bf16bits": bits(v),
+                    f"{name}_out": out.to(torch.float32), f"{name}_n_prev": np.int64(n_prev), f"{name}_W": np.int64(W)})
+    save("swa_attention_d128", names=np.array(names), **att)
+
+
+def gen_stack_realdims(ns):
+    """InfiniteVLDecoderLayer x 2 (1 sliding-window + 1 Gated DeltaNet) at the head shapes the HIP kernels are built
+    for: head_dim 128, linear_head_dim 128, expand_v 2 (K = 128, V = 256), mrope_section [16, 24, 24], window 96.
+    Weights and inputs are snapped to the bf16 grid, so the bf16 HIP stack runs on exactly these numbers; the reference
+    computes in fp32.  Same scenario as tiny_stack (prefill 70 -> 2 frames of 20 (window wraps) -> clone -> greedy
+    decode 6 -> one more frame).  Consumed DIRECTLY by tests/test_gpu_parity.py::test_stack_realdims_reference_vectors."""
+    print("[stack_realdims] reference decoder layers at K=128 / V=256 / d=128 (fp32, CPU, Triton interpreter)")
+    std = ns.std
+    from infinitevl.infinitevl_standard.configuration_infinitevl import InfiniteVLTextConfig
+    lt = ["sliding_attention", "linear_attention"]
+    cfg = InfiniteVLTextConfig(
+        vocab_size=97, hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+        num_key_value_heads=1, head_dim=128, rms_norm_eps=1e-6, norm_eps=1e-5, rope_theta=1e6, use_sliding_window=True,
+        sliding_window=96, max_window_layers=2, layer_types=list(lt), max_position_embeddings=4096,
+        rope_scaling={"type": "default", "rope_type": "default", "mrope_section": [16, 24, 24]},
+        num_linear_heads=2, num_linear_key_value_heads=2, linear_head_dim=128, expand_v=2, conv_size=4, pad_token_id=None)
+    torch.manual_seed(21)
+    layers = []
+    for i in range(2):
+        layer = std.InfiniteVLDecoderLayer(cfg, i)
+        with torch.no_grad():
+            for n, p_ in layer.named_parameters():
+                if n.endswith("A_log") or n.endswith("dt_bias"):
+                    pass
+                elif "layernorm" in n or "o_norm" in n:
+                    p_.copy_(1.0 + 0.1 * torch.randn_like(p_))
+                elif "conv1d" in n:
+                    p_.copy_(0.4 * torch.randn_like(p_))
+                elif n.endswith("bias"):
+                    p_.copy_(0.1 * torch.randn_like(p_))
+                else:
+                    p_.copy_(torch.randn_like(p_) * (p_.shape[-1] ** -0.5))
+                p_.copy_(snap(p_))
+        layer.eval()
+        layers.append(layer)
+    cfg._attn_implementation = "ivl_band"
+    rot = std.InfiniteVLRotaryEmbedding(cfg)
+    final_norm_w = snap(1.0 + 0.1 * torch.randn(256))
+    embed = snap(0.5 * torch.randn(97, 256))
+
+    def run_stack(x, pos3, cache, start):
+        T = x.shape[1]
+        pe = rot(x, pos3)
+        for layer in layers:
+            x = layer(x, attention_mask=None, position_ids=pos3, past_key_values=cache, use_cache=True,
+                      cache_position=torch.arange(start, start + T), position_embeddings=pe)[0]
+        xf = x.float()
+        return final_norm_w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps))
+
+    def pos_for(start, T):
+        return torch.arange(start, start + T)[None, None, :].expand(3, 1, T).contiguous()
+
+    out = {"layer_types": np.array(lt)}
+    for i, layer in enumerate(layers):
+        for k, v in layer.state_dict().items():
+            out[f"w.layers.{i}.{k}_bf16bits"] = bits(v)
+    out["w.norm.weight_bf16bits"] = bits(final_norm_w)
+    out["w.embed_tokens.weight_bf16bits"] = bits(embed)
+    with torch.no_grad():
+        cache = std.StaticCachePrealloc(config=cfg, batch_size=1, dtype=torch.float32)
+        ids0 = torch.randint(0, 97, (1, 70))
+        out["s.ids0"] = ids0.numpy()
+        out["s.h0"] = run_stack(embed[ids0], pos_for(0, 70), cache, 0).numpy()
+        pos = 70
+        frames = snap(0.5 * torch.randn(3, 1, 20, 256))
+        out["s.frames_bf16bits"] = bits(frames)
+        hs = []
+        for f in range(2):
+            h = run_stack(frames[f], pos_for(pos, 20), cache, pos)
+            hs.append(h.numpy())
+            pos += 20
+        out["s.h_frames"] = np.stack(hs)
+        import copy
+        qa = copy.deepcopy(cache)
+        tok = int((h[0, -1] @ embed.T).argmax())
+        out["s.first_token"] = np.int64(tok)
+        toks, logits, qpos = [], [], pos
+        for _ in range(6):
+            hq = run_stack(embed[torch.tensor([[tok]])], pos_for(qpos, 1), qa, qpos)
+            lg = hq[0, -1] @ embed.T
+            logits.append(lg.numpy())
+            tok = int(lg.argmax())
+            toks.append(tok)
+            qpos += 1
+        out["s.decode_tokens"] = np.array(toks)
+        out["s.decode_logits"] = np.stack(logits)
+        out["s.h_frame2_after_clone"] = run_stack(frames[2], pos_for(pos, 20), cache, pos).numpy()
+        out["s.swa_keys"] = cache.layers[0].keys.numpy()
+        out["s.swa_values"] = cache.layers[0].values.numpy()
+        out["s.swa_size"] = np.int64(cache.layers[0].size)
+        out["s.swa_cum"] = np.int64(cache.layers[0].cumulative_length)
+        out["s.gdn1_recurrent"] = cache.layers[1].recurrent_state.numpy()
+        out["s.gdn1_conv_q"] = cache.layers[1].conv_state_q.numpy()
+        # single mixers at the module boundary, no cache
+        x = snap(0.7 * torch.randn(1, 70, 256))
+        out["m.x_gdn_bf16bits"] = bits(x)
+        out["m.o_gdn"] = layers[1].self_attn(x, past_key_values=None)[0].numpy()
+        xs = snap(0.7 * torch.randn(1, 130, 256))
+        pos3 = torch.stack([torch.arange(130), torch.arange(130) // 3, torch.arange(130) % 5])[:, None, :].contiguous()
+        out["m.x_swa_bf16bits"] = bits(xs)
+        out["m.pos3"] = pos3.numpy()
+        out["m.o_swa"] = layers[0].self_attn(xs, attention_mask=None, position_ids=pos3, past_key_values=None,
+                                             cache_position=torch.arange(130), position_embeddings=rot(xs, pos3))[0].numpy()
+    save("stack_realdims", **out)
+
+
 def main():
     t0 = time.time()
     ns = load_reference_fla()
     ns = load_reference_std(ns)
     only = set(sys.argv[1:])
     steps = [("gdn", gen_gdn_ops), ("conv", gen_conv_norm), ("swa", gen_swa), ("cache", gen_cache_traces),
-             ("layers", gen_layers)]
+             ("layers", gen_layers), ("swa_d128", gen_swa_d128), ("stack_realdims", gen_stack_realdims)]
     for name, fn in steps:
         if only and name not in only:
             continue

@@ -198,3 +198,62 @@ def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3
     res["gdn_state"] = rms_rel(ocache[1].recurrent, cache.layers[1].recurrent_state.float())
     res["swa_keys"] = rms_rel(ocache[0].k, cache.layers[0].keys.float())
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] / SURVEY.md 8d cfg1: the single-image greedy-decode plumbing run
+# ---------------------------------------------------------------------------------------------
+def configs0_workload(hidden: int, vocab: int, seed: int = 0, n_text: int = 64, grid: int = 16):
+    """The shape of data/mllm_demo.json sample 0 after the processor (std:2112-2176; the ViT and the tokenizer are
+    out of scope and there is no checkpoint offline): `n_text` random token ids (seed 0) around a grid x grid block of
+    image-placeholder positions whose embeddings are replaced by randn * 0.02 "vision features".  Layout: 8 text tokens,
+    the image block, the remaining text.  position_ids are the 3-D (t, h, w) M-RoPE positions of Qwen2.5-VL's
+    get_rope_index: text advances all three together, the image block keeps t fixed and counts rows / columns.
+    Returns (ids [1,n_text], image_embeds [1,grid*grid,hidden] fp32 on the bf16 grid, is_image [T] bool, position_ids
+    [3,1,T] int64, next_position)."""
+    g_ = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, vocab, (1, n_text), generator=g_)
+    img = (torch.randn(1, grid * grid, hidden, generator=g_) * 0.02).to(torch.bfloat16).float()
+    n_img, pre = grid * grid, 8
+    T = n_text + n_img
+    is_image = torch.zeros(T, dtype=torch.bool)
+    is_image[pre:pre + n_img] = True
+    pos = torch.zeros(3, T, dtype=torch.int64)
+    pos[:, :pre] = torch.arange(pre)
+    rr, cc = torch.meshgrid(torch.arange(grid), torch.arange(grid), indexing="ij")
+    pos[0, pre:pre + n_img] = pre
+    pos[1, pre:pre + n_img] = pre + rr.flatten()
+    pos[2, pre:pre + n_img] = pre + cc.flatten()
+    nxt = pre + grid
+    pos[:, pre + n_img:] = nxt + torch.arange(T - pre - n_img)
+    return ids, img, is_image, pos[:, None, :].contiguous(), nxt + (T - pre - n_img)
+
+
+def configs0_embeds(embed: torch.Tensor, ids: torch.Tensor, img: torch.Tensor, is_image: torch.Tensor) -> torch.Tensor:
+    """inputs_embeds with the image features spliced over the placeholder positions (std:2140-2160)."""
+    T = is_image.numel()
+    x = torch.zeros(1, T, embed.shape[1], dtype=embed.dtype, device=embed.device)
+    x[0, ~is_image.to(embed.device)] = embed[ids[0].to(embed.device)]
+    x[0, is_image.to(embed.device)] = img[0].to(embed.device, embed.dtype)
+    return x
+
+
+def configs0_oracle_run(oc, params, n_new: int = 16, act_dtype=None, kernel_rounding=None, forced_tokens=None):
+    """Prefill + greedy decode of `n_new` tokens on the CPU oracle.  Returns (tokens, logits [n_new, vocab], cache)."""
+    embed = params["embed_tokens.weight"]
+    ids, img, is_image, pos3, nxt = configs0_workload(oc.hidden_size, embed.shape[0])
+    cache = omodel.new_cache(oc, cache_dtype=act_dtype)
+    x = configs0_embeds(embed, ids, img, is_image)
+    h = omodel.text_stack(params, x, pos3, oc, cache, act_dtype=act_dtype, kernel_rounding=kernel_rounding)
+    toks, logits = [], []
+    lg = h[0, -1].float() @ embed.float().T
+    for step in range(n_new):
+        logits.append(lg)
+        tok = int(lg.argmax())
+        toks.append(tok)
+        feed = tok if forced_tokens is None else int(forced_tokens[step])
+        pid = torch.full((3, 1, 1), nxt + step, dtype=torch.int64)
+        h = omodel.text_stack(params, embed[torch.tensor([[feed]])], pid, oc, cache, act_dtype=act_dtype,
+                              kernel_rounding=kernel_rounding)
+        lg = h[0, -1].float() @ embed.float().T
+    return toks, torch.stack(logits), cache

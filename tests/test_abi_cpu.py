@@ -177,6 +177,26 @@ def test_swa_ring_chronological_view_matches_reference_tail():
         off += n
 
 
+def test_swa_crop_matches_reference_trace():
+    """std:192-213 through the reference-generated trace: crop keeps the LAST new_size tokens and restarts the counters."""
+    from infinitevl_amd.cache import StaticSlidingWindowLayerPrealloc
+    z = load_golden("cache_traces")
+    layer = StaticSlidingWindowLayerPrealloc(config=_Cfg(), batch_size=1, device="cpu", dtype=torch.float32)
+    pos, off = 0, 0
+    for op, n, ctr in zip(z["crop_ops"].tolist(), z["crop_tail_lengths"].tolist(), z["crop_counters"].tolist()):
+        if op < 500:
+            for t in range(op):                      # what ivl_swa_cache_append writes (window not full: slot == position)
+                layer._buf_keys[:, :, (layer.cumulative_length + t) % layer.capacity, :] = float(pos + t)
+            layer.advance(op)
+            layer._pos_dev += op
+            pos += op
+        else:
+            layer.crop(op - 1000)
+        assert [layer.size, layer.cumulative_length] == ctr and int(layer._pos_dev) == ctr[1]
+        assert np.array_equal(layer.keys[0, 0, :, 0].numpy(), z["crop_tail_positions"].numpy()[off:off + n]), op
+        off += n
+
+
 def test_linear_layer_protocol_and_errors():
     from infinitevl_amd.cache import StaticLinearLayerPrealloc
     layer = StaticLinearLayerPrealloc(config=_Cfg(), batch_size=2, device="cpu", dtype=torch.float32, zero_init=True)

@@ -295,6 +295,19 @@ def test_swa_fp8_prefill_calls_stay_bf16():
     assert r["o"] < 5e-3, r
 
 
+def test_swa_reference_vectors_d128():
+    """Row S3 pinned DIRECTLY to the reference: outputs of the reference's eager_attention_forward (fp32, band mask from
+    the S2 predicate) at the kernel's head shape d = 128 -- GQA group 8 and 16-over-2 heads, empty / partly / fully cached,
+    decode, windows smaller and larger than the call -- fed to the operator-level entry point (concatenated K/V)."""
+    from infinitevl_amd import ops
+    z = load_golden("swa_attention_d128")
+    for name in [str(n) for n in z["names"]]:
+        q, k, v = (bf(z[name + s_]).to(DEV) for s_ in ("_q", "_k", "_v"))
+        out, _ = ops.swa_attention_interface(None, q, k, v, None, scaling=128 ** -0.5, sliding_window=int(z[name + "_W"]))
+        e = rms_rel(z[name + "_out"], out.float().cpu())
+        assert e < 5e-3, (name, e)
+
+
 def _band_counts(n_prev, T, W):
     """Decode WHICH keys each row attended: q = 0 makes the softmax uniform over the visible set, V holds
     one-hot residues of the key index, so out[i, r] * n_vis(i) = #visible keys with residue r."""
@@ -597,6 +610,113 @@ def test_swa_crop_keeps_the_last_tokens_like_the_reference():
     layer.update(bf(torch.randn(1, 2, 70, 128)).to(DEV), bf(torch.randn(1, 2, 70, 128)).to(DEV))
     with pytest.raises(ValueError):
         layer.crop(3)
+
+
+def test_stack_realdims_reference_vectors():
+    """Rows S0, G0 and H pinned DIRECTLY to the reference: `stack_realdims.npz` holds what the reference's own
+    InfiniteVLDecoderLayer / GatedDeltaNet / InfiniteVLSelfAttention / StaticCachePrealloc produce (fp32) at the head
+    shapes the kernels are built for, on bf16-representable weights and inputs; the drop-in modules run the same
+    scenario in bf16: prefill 70 -> two 20-token frames (the 96-key window wraps) -> cache clone -> greedy decode 6 ->
+    one more frame on the original.  Tolerance: bf16 activations through 2 decoder layers at width 256 sit ~1e-2 from the
+    fp32 reference (hidden states: 3e-2 bound); greedy tokens must agree wherever the reference's top-2 logit margin
+    exceeds 10x the logit error."""
+    from infinitevl_amd.harness import (InfiniteVLTextConfig, InfiniteVLTextStack, clone_inference_cache, greedy_decode)
+    z = load_golden("stack_realdims")
+    lt = [str(x) for x in z["layer_types"]]
+    hc = InfiniteVLTextConfig(vocab_size=97, hidden_size=256, intermediate_size=128, num_hidden_layers=2,
+                              num_attention_heads=2, num_key_value_heads=1, head_dim=128, sliding_window=96, layer_types=lt,
+                              num_linear_heads=2, num_linear_key_value_heads=2, linear_head_dim=128, rope_theta=1e6)
+    params = {k[2:]: v for k, v in z.items() if k.startswith("w.")}
+    for fuse in (False, True):
+        stack = InfiniteVLTextStack(hc)
+        parity.load_params(stack, params)
+        stack = stack.to(DEV, torch.bfloat16).eval()
+        if fuse:
+            stack.fuse_()
+        pid = lambda s0, T: torch.arange(s0, s0 + T, device=DEV)[None, None, :].expand(3, 1, T)    # noqa: E731
+        with torch.no_grad():
+            cache = stack.allocate_inference_cache(1)
+            h0, _ = stack(input_ids=z["s.ids0"].to(DEV), position_ids=pid(0, 70), past_key_values=cache)
+            assert rms_rel(z["s.h0"], h0.float().cpu()) < 3e-2, rms_rel(z["s.h0"], h0.float().cpu())
+            pos = 70
+            for f in range(2):
+                h, lg = stack(inputs_embeds=bf(z["s.frames"][f]).to(DEV), position_ids=pid(pos, 20), past_key_values=cache)
+                assert rms_rel(z["s.h_frames"][f], h.float().cpu()) < 3e-2, f
+                pos += 20
+            qa = clone_inference_cache(cache)
+            embed = params["embed_tokens.weight"]
+            tok, qpos = int(z["s.first_token"]), pos
+            for step in range(6):
+                _, lg = stack(input_ids=torch.tensor([[tok]], device=DEV), position_ids=pid(qpos, 1), past_key_values=qa)
+                ref_lg = z["s.decode_logits"][step]
+                err = float((lg[0, -1].float().cpu() - ref_lg).abs().max())
+                top2 = torch.topk(ref_lg, 2).values
+                if float(top2[0] - top2[1]) > 10 * err:
+                    assert int(lg[0, -1].argmax()) == int(z["s.decode_tokens"][step]), step
+                assert rms_rel(ref_lg, lg[0, -1].float().cpu()) < 5e-2, step
+                tok = int(z["s.decode_tokens"][step])          # teacher forcing: follow the reference's branch
+                qpos += 1
+            h3, _ = stack(inputs_embeds=bf(z["s.frames"][2]).to(DEV), position_ids=pid(pos, 20), past_key_values=cache)
+            assert rms_rel(z["s.h_frame2_after_clone"], h3.float().cpu()) < 3e-2
+            sw = cache.layers[0]
+            assert sw.size == int(z["s.swa_size"]) and sw.cumulative_length == int(z["s.swa_cum"])
+            assert rms_rel(z["s.swa_keys"], sw.keys.float().cpu()) < 2e-2
+            assert rms_rel(z["s.swa_values"], sw.values.float().cpu()) < 2e-2
+            assert rms_rel(z["s.gdn1_recurrent"], cache.layers[1].recurrent_state.float().cpu()) < 3e-2
+            # single mixers at the module boundary, no cache
+            og, _ = stack.layers[1].self_attn(bf(z["m.x_gdn"]).to(DEV), past_key_values=None)
+            assert rms_rel(z["m.o_gdn"], og.float().cpu()) < 2e-2, rms_rel(z["m.o_gdn"], og.float().cpu())
+            xs = bf(z["m.x_swa"]).to(DEV)
+            pos3 = z["m.pos3"].to(DEV)
+            pe = stack.rotary_emb(xs, pos3)
+            osw, _ = stack.layers[0].self_attn(xs, attention_mask=None, position_ids=pos3, past_key_values=None,
+                                               cache_position=torch.arange(130, device=DEV), position_embeddings=pe)
+            assert rms_rel(z["m.o_swa"], osw.float().cpu()) < 2e-2, rms_rel(z["m.o_swa"], osw.float().cpu())
+
+
+def test_configs0_plumbing_hip_stack_vs_cpu_path():
+    """BASELINE.json configs[0] on the HIP stack: the mllm_demo sample-0 shaped workload (64 random ids + 256 image
+    placeholder embeds, 3-D M-RoPE positions) through GatedDeltaNet / InfiniteVLSelfAttention / StaticCachePrealloc with
+    the infinitevl_standard signatures (one 4-layer period at InfiniteVL-3B's head shapes), greedy 16 tokens; the CPU
+    path (oracle, bf16 rounding model, teacher-forced on the HIP tokens) must produce the same token wherever its top-2
+    logit margin is unambiguous (> 10x the logit difference between the two paths)."""
+    from infinitevl_amd.harness import InfiniteVLTextConfig, InfiniteVLTextStack
+    from oracle import model as omodel
+    lt = ["sliding_attention", "linear_attention", "linear_attention", "linear_attention"]
+    oc = omodel.OracleConfig(hidden_size=2048, intermediate_size=2048, num_attention_heads=16, num_key_value_heads=2,
+                             num_linear_heads=16, linear_head_dim=128, expand_v=2.0, conv_size=4, sliding_window=4096,
+                             rope_theta=1e6, mrope_section=[16, 24, 24], layer_types=lt)
+    hc = InfiniteVLTextConfig(vocab_size=4096, hidden_size=2048, intermediate_size=2048, num_hidden_layers=4,
+                              sliding_window=4096, layer_types=lt)
+    params = parity.bf16_params(omodel.random_params(oc, seed=0, vocab=4096))
+    stack = InfiniteVLTextStack(hc)
+    parity.load_params(stack, params)
+    stack = stack.to(DEV, torch.bfloat16).eval().fuse_()
+    ids, img, is_image, pos3, nxt = parity.configs0_workload(2048, 4096)
+    with torch.no_grad():
+        cache = stack.allocate_inference_cache(1)
+        x = parity.configs0_embeds(stack.embed_tokens.weight, ids, img, is_image)
+        _, lg = stack(inputs_embeds=x, position_ids=pos3.to(DEV), past_key_values=cache)
+        toks, logits = [], []
+        for step in range(16):
+            logits.append(lg[0, -1].float().cpu())
+            tok = int(lg[0, -1].argmax())
+            toks.append(tok)
+            pid = torch.full((3, 1, 1), nxt + step, dtype=torch.int64, device=DEV)
+            _, lg = stack(input_ids=torch.tensor([[tok]], device=DEV), position_ids=pid, past_key_values=cache)
+    assert cache.get_seq_length() == 336 and cache.layers[0].size == 336
+    assert all(torch.isfinite(l).all() for l in logits)
+    otoks, ologits, _ = parity.configs0_oracle_run(oc, params, act_dtype=torch.bfloat16, kernel_rounding=torch.bfloat16,
+                                                   forced_tokens=toks)
+    checked = 0
+    for step in range(16):
+        err = float((ologits[step] - logits[step]).abs().max())
+        top2 = torch.topk(ologits[step], 2).values
+        if float(top2[0] - top2[1]) > 10 * err:
+            assert otoks[step] == toks[step], step
+            checked += 1
+        assert rms_rel(ologits[step], logits[step]) < 5e-2, (step, rms_rel(ologits[step], logits[step]))
+    assert checked >= 4, checked
 
 
 def test_clone_branch_decode_then_resume_stream():

@@ -106,6 +106,15 @@ def test_swa_attention_matches_reference():
         assert rms_rel(z[name + "_out"], out) < 2e-6, name
 
 
+def test_swa_attention_d128_matches_reference():
+    """The head shape the HIP kernel is built for (d = 128, GQA group 8 / 16-over-2 heads), windows smaller and larger
+    than the call."""
+    z = load_golden("swa_attention_d128")
+    for name in [str(n) for n in z["names"]]:
+        out = swa.swa_attention(z[name + "_q"], z[name + "_k"], z[name + "_v"], int(z[name + "_n_prev"]), int(z[name + "_W"]))
+        assert rms_rel(z[name + "_out"], out) < 2e-6, name
+
+
 def test_mrope_matches_reference():
     z = load_golden("mrope")
     cos, sin = swa.rotary_cos_sin(z["position_ids"], 128, float(z["theta"]))
@@ -177,6 +186,55 @@ def test_tiny_stack_harness_matches_reference():
     assert cache[1].counters.seq_len == int(z["s.gdn1_seq_len"])
 
 
+def _realdims():
+    z = load_golden("stack_realdims")
+    lt = [str(x) for x in z["layer_types"]]
+    cfg = model.OracleConfig(hidden_size=256, intermediate_size=128, num_attention_heads=2, num_key_value_heads=1,
+                             num_linear_heads=2, linear_head_dim=128, expand_v=2, conv_size=4, sliding_window=96,
+                             rope_theta=1e6, mrope_section=[16, 24, 24], layer_types=lt)
+    params = {k[2:]: v for k, v in z.items() if k.startswith("w.")}
+    return z, cfg, params
+
+
+def test_stack_realdims_matches_reference():
+    """The same harness scenario as tiny_stack on reference decoder layers with the REAL head shapes (head_dim 128,
+    K = 128, V = 256, mrope [16,24,24], window 96 that wraps during the stream)."""
+    z, cfg, p = _realdims()
+    embed = p["embed_tokens.weight"]
+    cache = model.new_cache(cfg)
+    h0 = model.text_stack(p, embed[z["s.ids0"]], _pos(0, 70), cfg, cache)
+    assert rms_rel(z["s.h0"], h0) < 1e-5, rms_rel(z["s.h0"], h0)
+    pos = 70
+    for f in range(2):
+        h = model.text_stack(p, z["s.frames"][f], _pos(pos, 20), cfg, cache)
+        assert rms_rel(z["s.h_frames"][f], h) < 1e-5, f
+        pos += 20
+    qa = model.clone_cache(cache)
+    tok = int((h[0, -1] @ embed.T).argmax())
+    assert tok == int(z["s.first_token"])
+    qpos = pos
+    for step in range(6):
+        hq = model.text_stack(p, embed[torch.tensor([[tok]])], _pos(qpos, 1), cfg, qa)
+        lg = hq[0, -1] @ embed.T
+        assert rms_rel(z["s.decode_logits"][step], lg) < 1e-5
+        tok = int(lg.argmax())
+        assert tok == int(z["s.decode_tokens"][step])
+        qpos += 1
+    h3 = model.text_stack(p, z["s.frames"][2], _pos(pos, 20), cfg, cache)
+    assert rms_rel(z["s.h_frame2_after_clone"], h3) < 1e-5
+    sw = cache[0]
+    assert sw.counters.size == int(z["s.swa_size"]) == 95 and sw.counters.cumulative_length == int(z["s.swa_cum"]) == 130
+    assert rms_rel(z["s.swa_keys"], sw.k) < 1e-5 and rms_rel(z["s.swa_values"], sw.v) < 1e-5
+    assert rms_rel(z["s.gdn1_recurrent"], cache[1].recurrent) < 1e-5
+    assert rms_rel(z["s.gdn1_conv_q"], cache[1].conv[0]) < 1e-6
+    # single mixers at the module boundary
+    o = model.gdn_layer(model._sub(p, "layers.1.self_attn."), z["m.x_gdn"], cfg, None)
+    assert rms_rel(z["m.o_gdn"], o) < 1e-5
+    cos, sin = swa.rotary_cos_sin(z["m.pos3"], cfg.head_dim, cfg.rope_theta)
+    o = model.swa_layer(model._sub(p, "layers.0.self_attn."), z["m.x_swa"], cos, sin, cfg, None)
+    assert rms_rel(z["m.o_swa"], o) < 1e-5
+
+
 def test_tiny_mixers_match_reference():
     z, cfg, p = _tiny()
     zm = load_golden("tiny_mixers")
@@ -187,3 +245,25 @@ def test_tiny_mixers_match_reference():
     cos, sin = swa.rotary_cos_sin(zm["pos3"], cfg.head_dim, cfg.rope_theta)
     o = model.swa_layer(ps, zm["x_swa"], cos, sin, cfg, None)
     assert rms_rel(zm["o_swa"], o) < 1e-5, rms_rel(zm["o_swa"], o)
+
+
+def test_configs0_plumbing_run_on_the_cpu_path():
+    """BASELINE.json configs[0]: "mllm_demo.json single-image greedy decode on CPU eager path
+    (plumbing, no GPU)".  The workload of sample 0 after the processor -- 64 random ids + 256 image-placeholder embeds
+    with (t, h, w) M-RoPE positions -- through the CPU restatement of the path with the infinitevl_standard layer
+    semantics (one 4-layer period: 1 sliding-window + 3 Gated DeltaNet decoder layers at InfiniteVL-3B's head shapes,
+    window 4096), greedy 16 tokens.  Asserts plumbing only: shapes, finiteness, counters, determinism.  The GPU twin
+    (tests/test_gpu_parity.py::test_configs0_plumbing_hip_stack_vs_cpu_path) runs the HIP stack on the same workload."""
+    import parity
+    lt = ["sliding_attention", "linear_attention", "linear_attention", "linear_attention"]
+    oc = model.OracleConfig(hidden_size=2048, intermediate_size=2048, num_attention_heads=16, num_key_value_heads=2,
+                            num_linear_heads=16, linear_head_dim=128, expand_v=2.0, conv_size=4, sliding_window=4096,
+                            rope_theta=1e6, mrope_section=[16, 24, 24], layer_types=lt)
+    params = model.random_params(oc, seed=0, vocab=4096)
+    toks, logits, cache = parity.configs0_oracle_run(oc, params)
+    assert len(toks) == 16 and all(0 <= t < 4096 for t in toks)
+    assert tuple(logits.shape) == (16, 4096) and bool(torch.isfinite(logits).all())
+    assert cache[0].counters.cumulative_length == 320 + 16 and cache[0].counters.size == 320 + 16    # window 4096 not full
+    assert cache[1].counters.seq_len > 0
+    toks2, _, _ = parity.configs0_oracle_run(oc, params)
+    assert toks == toks2
