@@ -679,20 +679,22 @@ def test_configs0_plumbing_hip_stack_vs_cpu_path():
     placeholder embeds, 3-D M-RoPE positions) through GatedDeltaNet / InfiniteVLSelfAttention / StaticCachePrealloc with
     the infinitevl_standard signatures (one 4-layer period at InfiniteVL-3B's head shapes), greedy 16 tokens; the CPU
     path (oracle, bf16 rounding model, teacher-forced on the HIP tokens) must produce the same token wherever its top-2
-    logit margin is unambiguous (> 10x the logit difference between the two paths)."""
+    logit margin is unambiguous (more than twice the largest logit difference between the two paths: then no flip is
+    possible).  A 128-entry vocabulary keeps such margins frequent with random-init weights: among 151936 near-flat
+    logits no argmax would be unambiguous."""
     from infinitevl_amd.harness import InfiniteVLTextConfig, InfiniteVLTextStack
     from oracle import model as omodel
     lt = ["sliding_attention", "linear_attention", "linear_attention", "linear_attention"]
     oc = omodel.OracleConfig(hidden_size=2048, intermediate_size=2048, num_attention_heads=16, num_key_value_heads=2,
                              num_linear_heads=16, linear_head_dim=128, expand_v=2.0, conv_size=4, sliding_window=4096,
                              rope_theta=1e6, mrope_section=[16, 24, 24], layer_types=lt)
-    hc = InfiniteVLTextConfig(vocab_size=4096, hidden_size=2048, intermediate_size=2048, num_hidden_layers=4,
+    hc = InfiniteVLTextConfig(vocab_size=128, hidden_size=2048, intermediate_size=2048, num_hidden_layers=4,
                               sliding_window=4096, layer_types=lt)
-    params = parity.bf16_params(omodel.random_params(oc, seed=0, vocab=4096))
+    params = parity.bf16_params(omodel.random_params(oc, seed=0, vocab=128))
     stack = InfiniteVLTextStack(hc)
     parity.load_params(stack, params)
     stack = stack.to(DEV, torch.bfloat16).eval().fuse_()
-    ids, img, is_image, pos3, nxt = parity.configs0_workload(2048, 4096)
+    ids, img, is_image, pos3, nxt = parity.configs0_workload(2048, 128)
     with torch.no_grad():
         cache = stack.allocate_inference_cache(1)
         x = parity.configs0_embeds(stack.embed_tokens.weight, ids, img, is_image)
@@ -708,15 +710,17 @@ def test_configs0_plumbing_hip_stack_vs_cpu_path():
     assert all(torch.isfinite(l).all() for l in logits)
     otoks, ologits, _ = parity.configs0_oracle_run(oc, params, act_dtype=torch.bfloat16, kernel_rounding=torch.bfloat16,
                                                    forced_tokens=toks)
-    checked = 0
+    checked, info = 0, []
     for step in range(16):
         err = float((ologits[step] - logits[step]).abs().max())
         top2 = torch.topk(ologits[step], 2).values
-        if float(top2[0] - top2[1]) > 10 * err:
-            assert otoks[step] == toks[step], step
+        info.append((round(float(top2[0] - top2[1]), 4), round(err, 4), otoks[step] == toks[step]))
+        if float(top2[0] - top2[1]) > 2 * err:      # the other path cannot flip the argmax: 2 x max|dlogit| < margin
+            assert otoks[step] == toks[step], (step, info)
             checked += 1
         assert rms_rel(ologits[step], logits[step]) < 5e-2, (step, rms_rel(ologits[step], logits[step]))
-    assert checked >= 4, checked
+    print("configs0 (margin, max|dlogit|, same token):", info)
+    assert checked >= 3, info
 
 
 def test_clone_branch_decode_then_resume_stream():
