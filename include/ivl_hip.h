@@ -155,6 +155,10 @@ typedef struct ivl_swa_args {
   float scaling;
   void* workspace;
   size_t workspace_bytes;
+  const void* rope_cos;     /* optional fused M-RoPE (std:949-984): cos / sin tables bf16 [3,B,T,d] as produced by  */
+  const void* rope_sin;     /* InfiniteVLRotaryEmbedding; q and k_new are then the UN-rotated projections and are rotated while   */
+  int rope_s0, rope_s1;     /* they are loaded (bit-identical to ivl_mrope_fwd).  Needs T_new == T; sections s0|s1|rest, multiples */
+                            /* of 8.  NULL: q / k_new are already rotated.                                                         */
   int mma_dtype;            /* IVL_BF16 (the reference's precision) or IVL_FP8_E4M3: the single-token decode step
                                (T * Hq/Hkv <= 64 packed rows) rounds q, K, V and the probabilities to e4m3 for the two
                                products (BASELINE.json configs[4]); longer calls always run in bf16                  */
@@ -164,10 +168,12 @@ IVL_API size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);
 IVL_API int ivl_swa_fwd(const ivl_swa_args* args, void* stream);
 
 /* Append the T new tokens to the ring (slot (pos+t) % C) -- after ivl_swa_fwd of the same call.
- * Replaces the tail copy-back of std:146-172.  k_new,v_new bf16 with the strides given. */
+ * Replaces the tail copy-back of std:146-172.  k_new,v_new bf16 with the strides given.  With rope_cos / rope_sin
+ * (same meaning as in ivl_swa_args) the keys are rotated on the way into the ring. */
 IVL_API int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
                          void* k_cache, void* v_cache, int B, int T, int Hkv, int d, int cache_capacity,
-                         int64_t pos, const int64_t* pos_dev, void* stream);
+                         int64_t pos, const int64_t* pos_dev, const void* rope_cos, const void* rope_sin,
+                         int rope_s0, int rope_s1, void* stream);
 
 /* *counter += delta on the device (graph-replayable position bookkeeping). */
 IVL_API int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);

@@ -39,6 +39,7 @@ class SwaArgs(Structure):
         ("pos", c_int64), ("pos_dev", c_void_p),
         ("scaling", c_float),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_s0", c_int), ("rope_s1", c_int),
         ("mma_dtype", c_int),
     ]
 
@@ -89,7 +90,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_swa_fwd.restype = i
     lib.ivl_swa_fwd.argtypes = [POINTER(SwaArgs), vp]
     lib.ivl_swa_cache_append.restype = i
-    lib.ivl_swa_cache_append.argtypes = [vp, vp, i64, i64, i64, vp, vp, i, i, i, i, i, i64, vp, vp]
+    lib.ivl_swa_cache_append.argtypes = [vp, vp, i64, i64, i64, vp, vp, i, i, i, i, i, i64, vp, vp, vp, i, i, vp]
     lib.ivl_counter_add.restype = i
     lib.ivl_counter_add.argtypes = [vp, i64, vp]
     lib.ivl_gdn_prologue_fwd.restype = i

@@ -70,6 +70,9 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         else:
             self._buf_keys = self._buf_values = None
         self._pos_dev = torch.zeros(1, dtype=torch.int64, device=device)     # == cumulative_length, on device
+        # Inside a StaticCachePrealloc all sliding layers share ONE device counter (they always hold the same value) and
+        # only the last of them advances it, once per forward: one counter launch per step instead of one per layer.
+        self._advances_counter = True
 
     # ---- chronological views (reference attribute names; materialised on demand) -------------
     def _chronological(self, buf: torch.Tensor) -> torch.Tensor:
@@ -102,8 +105,9 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         return self.keys, self.values
 
     def attend(self, q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, scaling: float,
-               window: Optional[int], mma_dtype=None) -> torch.Tensor:
-        """q [B,T,Hq,d], k_new/v_new [B,T,Hkv,d] (time-major, post-RoPE).  Attention over
+               window: Optional[int], mma_dtype=None, rope=None) -> torch.Tensor:
+        """q [B,T,Hq,d], k_new/v_new [B,T,Hkv,d] (time-major; post-RoPE, or the raw projections together with
+        rope=(cos, sin, mrope_section): the kernels then rotate q / k while loading them).  Attention over
         (ring ++ new) with the band of SURVEY.md section 8a S2, then append + advance.  Returns [B,T,Hq,d]."""
         B, T, Hkv, D = k_new.shape
         if B != self.batch_size:
@@ -111,10 +115,12 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         if Hkv != self.num_kv_heads or D != self.head_dim:
             raise ValueError(f"SWA head dim mismatch: got H={Hkv},D={D}, expect H={self.num_kv_heads},D={self.head_dim}")
         o = ops.swa_forward(q, k_new, v_new, window=window, scaling=scaling,
-                            k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev, mma_dtype=mma_dtype)
+                            k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev, mma_dtype=mma_dtype,
+                            rope=rope)
         if self.capacity > 0:
-            ops.swa_cache_append(k_new, v_new, self._buf_keys, self._buf_values, pos_dev=self._pos_dev)
-        ops.counter_add(self._pos_dev, T)
+            ops.swa_cache_append(k_new, v_new, self._buf_keys, self._buf_values, pos_dev=self._pos_dev, rope=rope)
+        if self._advances_counter:
+            ops.counter_add(self._pos_dev, T)
         self.advance(T)
         return o
 
@@ -138,7 +144,8 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         if self.capacity > 0:
             ops.swa_cache_append(key_states.transpose(1, 2), value_states.transpose(1, 2),
                                  self._buf_keys, self._buf_values, pos_dev=self._pos_dev)
-        ops.counter_add(self._pos_dev, Tq)
+        if self._advances_counter:
+            ops.counter_add(self._pos_dev, Tq)
         self.advance(Tq)
         return full_k, full_v
 
@@ -498,6 +505,16 @@ class StaticCachePrealloc(_HFCache):
                 super().__init__(layers=layers)
         self.layers = layers
         self.layer_types = list(layer_types)
+        self._share_position_counter()
+
+    def _share_position_counter(self) -> None:
+        """All sliding layers of one cache see the same number of tokens: point them at ONE device counter, advanced by
+        the last sliding layer only (the decoder runs the layers in order, so every layer has read it by then)."""
+        sliding = [l for l in self.layers if isinstance(l, StaticSlidingWindowLayerPrealloc)]
+        for i, layer in enumerate(sliding):
+            if i > 0:
+                layer._pos_dev = sliding[0]._pos_dev
+            layer._advances_counter = i == len(sliding) - 1
 
     def update(self, layer_idx: int, key_states=None, value_states=None, conv_state=None, recurrent_state=None,
                cache_kwargs: Optional[dict[str, Any]] = None):
@@ -525,6 +542,7 @@ class StaticCachePrealloc(_HFCache):
     def clone(self) -> "StaticCachePrealloc":
         new = copy.copy(self)
         new.layers = [layer.clone() for layer in self.layers]
+        new._share_position_counter()
         return new
 
     def copy_from(self, other: "StaticCachePrealloc") -> None:

@@ -38,6 +38,8 @@ struct SwaParams {
   long long pos; const long long* pos_dev;
   float scaling;
   float* part_o; float* part_ml;
+  // M-RoPE fused into the Q load and the staging of the call's new keys (NULL: inputs are already rotated)
+  const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
 };
 
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
@@ -74,6 +76,30 @@ __device__ __forceinline__ float group_sum(float x) {
   x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// M-RoPE (std:949-984) on one pair of 8-channel groups of one row: channels c0..c0+7 ("lo") and c0+64..c0+71 ("hi").
+// cos/sin: [3, B, T, 128] bf16 tables (t, h, w); the channel block selects its table by the mrope sections (s0 | s1 | rest,
+// multiples of 8).  Products and the sum are each rounded to bf16 like the reference's eager bf16 arithmetic: bit-identical
+// to ivl_mrope_fwd.  `row_off` = (b * T + t) * 128, `plane` = B * T * 128.
+__device__ __forceinline__ void rope_pair(u32x4& lo, u32x4& hi, const bf16_t* cosp, const bf16_t* sinp, long long plane,
+                                          long long row_off, int c0, int s0, int s1) {
+  const int sec = c0 < s0 ? 0 : (c0 < s0 + s1 ? 1 : 2);
+  const long long off = sec * plane + row_off + c0;
+  const u32x4 c1 = *(const u32x4*)(cosp + off), n1 = *(const u32x4*)(sinp + off);
+  const u32x4 c2 = *(const u32x4*)(cosp + off + 64), n2 = *(const u32x4*)(sinp + off + 64);
+  const unsigned int x1[4] = {lo.x, lo.y, lo.z, lo.w}, x2[4] = {hi.x, hi.y, hi.z, hi.w};
+  const unsigned int cc1[4] = {c1.x, c1.y, c1.z, c1.w}, nn1[4] = {n1.x, n1.y, n1.z, n1.w};
+  const unsigned int cc2[4] = {c2.x, c2.y, c2.z, c2.w}, nn2[4] = {n2.x, n2.y, n2.z, n2.w};
+  unsigned int o1[4], o2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = bflo(x1[i]), a1 = bfhi(x1[i]), b0 = bflo(x2[i]), b1 = bfhi(x2[i]);
+    o1[i] = pack2bf(bf_round(a0 * bflo(cc1[i])) + bf_round(-b0 * bflo(nn1[i])), bf_round(a1 * bfhi(cc1[i])) + bf_round(-b1 * bfhi(nn1[i])));
+    o2[i] = pack2bf(bf_round(b0 * bflo(cc2[i])) + bf_round(a0 * bflo(nn2[i])), bf_round(b1 * bfhi(cc2[i])) + bf_round(a1 * bfhi(nn2[i])));
+  }
+  lo = u32x4{o1[0], o1[1], o1[2], o1[3]};
+  hi = u32x4{o2[0], o2[1], o2[2], o2[3]};
 }
 
 template <bool PACK, int QG>
@@ -166,6 +192,15 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
     }
   }
 
+  const long long rplane = (long long)p.B * p.T * SWA_D;
+  if (p.rcos != nullptr) {
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      const long long row_off = ((long long)b * p.T + min(t_row[qg], p.T - 1)) * SWA_D;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) rope_pair(qf[qg][ks], qf[qg][ks + 2], p.rcos, p.rsin, rplane, row_off, 32 * ks + 8 * g, p.rs0, p.rs1);
+    }
+  }
   float m_run[QG], l_run[QG];
   f32x4 oacc[QG][8];
 #pragma unroll
@@ -185,6 +220,15 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   const bf16_t* kb_new = p.k_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
   const bf16_t* vb_new = p.v_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh + schunk * 8;
   const unsigned int kn_st32 = (unsigned int)p.kn_st;
+  // the call's new keys arrive un-rotated when the rope is fused: thread (row, 16-byte chunk) fetches the partner chunk
+  // (channels +-64) and the row's cos / sin and rotates its chunk in place (only the few tiles that hold new keys pay this)
+  auto rope_new_key = [&](u32x4& kv, int jn /* index among the new keys */) {
+    const int lo_ch = (schunk & 7) * 8;                    // channel block of the "lo" half of the pair
+    const u32x4 part = *(const u32x4*)(kb_new - schunk * 8 + (unsigned int)jn * kn_st32 + (schunk ^ 8) * 8);
+    u32x4 lo = schunk < 8 ? kv : part, hi = schunk < 8 ? part : kv;
+    rope_pair(lo, hi, p.rcos, p.rsin, rplane, ((long long)b * p.T + jn) * SWA_D, lo_ch, p.rs0, p.rs1);
+    kv = schunk < 8 ? lo : hi;
+  };
   auto load_tile = [&](int kt) {
     const int j0 = kt * SWA_KT;
     const int slot0 = s0 + j0;
@@ -206,6 +250,10 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
         kreg[i] = *(const u32x4*)(kb_new + off + 16 * i * kn_st32);
         vreg[i] = *(const u32x4*)(vb_new + off + 16 * i * kn_st32);
       }
+      if (p.rcos != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rope_new_key(kreg[i], j0 - n_ring + srow + 16 * i);
+      }
       return;
     }
     // generic tile (ring wrap, ring/new seam or tail).  Branch-free per row: every row issues its two 16-byte
@@ -222,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
       const bf16_t* vp = (in_ring ? vb_ring : vb_new) + off;
       kreg[i] = *(const u32x4*)kp;
       vreg[i] = *(const u32x4*)vp;
+      if (p.rcos != nullptr && !in_ring) rope_new_key(kreg[i], jc - n_ring);
     }
     if (j0 + SWA_KT > S) {          // wave-uniform: tail tile, rows >= S are zeroed
 #pragma unroll
@@ -644,7 +693,7 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
 __global__ __launch_bounds__(256) void swa_cache_append_kernel(
     const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, long long kn_sb, long long kn_st, long long kn_sh,
     bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int B, int T, int Hkv, int C,
-    long long pos_host, const long long* pos_dev) {
+    long long pos_host, const long long* pos_dev, const bf16_t* __restrict__ rcos, const bf16_t* __restrict__ rsin, int rs0, int rs1) {
   const long long pos = pos_dev ? *pos_dev : pos_host;
   const int t_first = T > C ? T - C : 0;
   const int nt = T - t_first;
@@ -658,7 +707,14 @@ __global__ __launch_bounds__(256) void swa_cache_append_kernel(
     const int slot = (int)((pos + tt) % C);
     const long long src = (long long)b * kn_sb + (long long)tt * kn_st + (long long)hk * kn_sh + ch * 8;
     const long long dst = (((long long)b * Hkv + hk) * C + slot) * SWA_D + ch * 8;
-    *(u32x4*)(k_cache + dst) = *(const u32x4*)(k_new + src);
+    u32x4 kv = *(const u32x4*)(k_new + src);
+    if (rcos != nullptr) {                       // rotate on the way into the ring (same arithmetic as the attention kernel)
+      const u32x4 part = *(const u32x4*)(k_new + src + ((ch ^ 8) - ch) * 8);
+      u32x4 lo = ch < 8 ? kv : part, hi = ch < 8 ? part : kv;
+      rope_pair(lo, hi, rcos, rsin, (long long)B * T * SWA_D, ((long long)b * T + tt) * SWA_D, (ch & 7) * 8, rs0, rs1);
+      kv = ch < 8 ? lo : hi;
+    }
+    *(u32x4*)(k_cache + dst) = kv;
     *(u32x4*)(v_cache + dst) = *(const u32x4*)(v_new + src);
   }
 }
@@ -699,6 +755,13 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   IVL_REQUIRE(a->cache_capacity >= 0 && (a->cache_capacity == 0 || (a->k_cache && a->v_cache)), IVL_ERR_INVALID_ARG,
               "ivl_swa_fwd: cache_capacity=%d needs k_cache/v_cache", a->cache_capacity);
   IVL_REQUIRE(a->pos_dev != nullptr || a->pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_fwd: negative pos");
+  IVL_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), IVL_ERR_INVALID_ARG, "ivl_swa_fwd: rope_cos and rope_sin go together");
+  IVL_REQUIRE(a->rope_cos == nullptr || (a->T_new == a->T && a->rope_s0 % 8 == 0 && a->rope_s1 % 8 == 0 && a->rope_s0 >= 0 &&
+                                          a->rope_s1 >= 0 && a->rope_s0 + a->rope_s1 <= 64),
+              IVL_ERR_UNSUPPORTED, "ivl_swa_fwd: fused rope needs T_new == T and mrope sections that are multiples of 8 (got %d, %d)",
+              a->rope_s0, a->rope_s1);
+  IVL_REQUIRE(a->rope_cos == nullptr || a->mma_dtype == IVL_BF16 || !((long long)a->T * (a->Hq / a->Hkv) <= SWA_QT),
+              IVL_ERR_UNSUPPORTED, "ivl_swa_fwd: the fp8 decode step takes rotated q / k (apply ivl_mrope_fwd first)");
   IVL_REQUIRE(a->mma_dtype == IVL_BF16 || a->mma_dtype == IVL_FP8_E4M3, IVL_ERR_INVALID_ARG,
               "ivl_swa_fwd: mma_dtype must be IVL_BF16 or IVL_FP8_E4M3 (got %d)", a->mma_dtype);
   // new-key rows are addressed with 32-bit element offsets from the (batch, kv-head) base
@@ -730,6 +793,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.B = a->B; p.T = a->T; p.T_new = a->T_new; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity; p.W = a->window;
   p.nsplit = nsplit; p.pos = a->pos; p.pos_dev = (const long long*)a->pos_dev; p.scaling = a->scaling;
   p.part_o = nullptr; p.part_ml = nullptr;
+  p.rcos = (const bf16_t*)a->rope_cos; p.rsin = (const bf16_t*)a->rope_sin; p.rs0 = a->rope_s0; p.rs1 = a->rope_s1;
   if (nsplit > 1) {
     const size_t n_o = (size_t)a->B * nsplit * a->T * a->Hq * SWA_D;
     const size_t need = (n_o + (size_t)a->B * nsplit * a->T * a->Hq * 2) * sizeof(float);
@@ -765,17 +829,22 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
 
 extern "C" int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t kn_sb, int64_t kn_st, int64_t kn_sh,
                                     void* k_cache, void* v_cache, int B, int T, int Hkv, int d, int cache_capacity,
-                                    int64_t pos, const int64_t* pos_dev, void* stream) {
+                                    int64_t pos, const int64_t* pos_dev, const void* rope_cos, const void* rope_sin,
+                                    int rope_s0, int rope_s1, void* stream) {
   IVL_REQUIRE(k_new && v_new && k_cache && v_cache, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: NULL pointer");
   IVL_REQUIRE(B > 0 && T > 0 && Hkv > 0 && cache_capacity > 0, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: bad sizes");
   IVL_REQUIRE(d == SWA_D, IVL_ERR_UNSUPPORTED, "ivl_swa_cache_append: head_dim %d unsupported", d);
   IVL_REQUIRE(pos_dev != nullptr || pos >= 0, IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: negative pos");
+  IVL_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), IVL_ERR_INVALID_ARG, "ivl_swa_cache_append: rope_cos and rope_sin go together");
+  IVL_REQUIRE(rope_cos == nullptr || (rope_s0 % 8 == 0 && rope_s1 % 8 == 0 && rope_s0 >= 0 && rope_s1 >= 0 && rope_s0 + rope_s1 <= 64),
+              IVL_ERR_UNSUPPORTED, "ivl_swa_cache_append: mrope sections must be multiples of 8 (got %d, %d)", rope_s0, rope_s1);
   const int nt = T > cache_capacity ? cache_capacity : T;
   long long items = (long long)B * nt * Hkv * (SWA_D / 8);
   long long gb = (items + 255) / 256;
   if (gb > 2048) gb = 2048;
   hipLaunchKernelGGL(swa_cache_append_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)k_new, (const bf16_t*)v_new, (long long)kn_sb, (long long)kn_st, (long long)kn_sh,
-                     (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, Hkv, cache_capacity, (long long)pos, (const long long*)pos_dev);
+                     (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, Hkv, cache_capacity, (long long)pos, (const long long*)pos_dev,
+                     (const bf16_t*)rope_cos, (const bf16_t*)rope_sin, rope_s0, rope_s1);
   return check_launch("ivl_swa_cache_append");
 }

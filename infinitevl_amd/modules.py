@@ -105,24 +105,34 @@ class InfiniteVLSelfAttention(nn.Module):
         bsz, q_len, _ = hidden_states.size()
         cos, sin = position_embeddings
         # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
+        layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
+        sec = self.rope_scaling["mrope_section"]
+        native = layer is None or isinstance(layer, StaticSlidingWindowLayerPrealloc)
+        # M-RoPE is fused into the attention / append kernels (q and k are rotated while they are loaded: no separate
+        # launch, bit-identical) whenever our own cache (or none) is used; the fp8 decode step and the foreign-cache
+        # protocol take rotated tensors
+        fuse_rope = (native and self.head_dim == 128 and sec[0] % 8 == 0 and sec[1] % 8 == 0 and cos.shape[0] == 3
+                     and not (self.mma_dtype is not None and q_len * self.num_key_value_groups <= 64))
         if self._fused_ok(hidden_states):
             nq, nkv = self.num_heads * self.head_dim, self.num_key_value_heads * self.head_dim
             qkv = ops.linear(hidden_states, self._fused_w, self._fused_b)                     # [B,T,nq+2nkv]
             q = qkv[..., :nq].unflatten(-1, (self.num_heads, self.head_dim))
             k = qkv[..., nq:nq + nkv].unflatten(-1, (self.num_key_value_heads, self.head_dim))
             v = qkv[..., nq + nkv:].unflatten(-1, (self.num_key_value_heads, self.head_dim))
-            ops.apply_mrope_strided_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])
+            if not fuse_rope:
+                ops.apply_mrope_strided_inplace(q, k, cos, sin, sec)
         else:
             q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
             k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
             v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-            ops.apply_mrope_inplace(q, k, cos, sin, self.rope_scaling["mrope_section"])   # std:1057-1064
+            if not fuse_rope:
+                ops.apply_mrope_inplace(q, k, cos, sin, sec)                                  # std:1057-1064
+        rope = (cos, sin, sec) if fuse_rope else None
 
-        layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
         if isinstance(layer, StaticSlidingWindowLayerPrealloc):
-            attn = layer.attend(q, k, v, self.scaling, self.sliding_window, mma_dtype=self.mma_dtype)   # std:1067-1108 fused
+            attn = layer.attend(q, k, v, self.scaling, self.sliding_window, mma_dtype=self.mma_dtype, rope=rope)   # std:1067-1108 fused
         elif layer is None:
-            attn = ops.swa_forward(q, k, v, window=self.sliding_window, scaling=self.scaling)
+            attn = ops.swa_forward(q, k, v, window=self.sliding_window, scaling=self.scaling, rope=rope)
         else:  # foreign cache object: go through the reference protocol (cat of cached + new)
             fk, fv = past_key_values.update(layer_idx=self.layer_idx, key_states=k.transpose(1, 2),
                                             value_states=v.transpose(1, 2), conv_state=None, recurrent_state=None,

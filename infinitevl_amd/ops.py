@@ -449,13 +449,15 @@ def swa_forward(
     q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, *, window: Optional[int], scaling: float,
     k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
     pos: int = 0, pos_dev: Optional[torch.Tensor] = None, n_query: Optional[int] = None,
-    layout: str = "bthd", mma_dtype=None,
+    layout: str = "bthd", mma_dtype=None, rope=None,
 ) -> torch.Tensor:
     """Sliding-window GQA attention over (ring cache ++ new keys); returns o [B,T,Hq,d] bf16.
 
     layout "bthd": q [B,T,Hq,d], k_new/v_new [B,T_new,Hkv,d]; "bhtd": head-major views
     (any strides with a contiguous last dim are accepted -- no copies are made).
-    `n_query` = T (defaults to q's length); T_new >= T, the first T_new-T new keys being older keys."""
+    `n_query` = T (defaults to q's length); T_new >= T, the first T_new-T new keys being older keys.
+    `rope=(cos, sin, mrope_section)` (cos/sin bf16 [3,B,T,d]): q and k_new are the UN-rotated projections and M-RoPE
+    (std:949-984) is applied while they are loaded -- bit-identical to apply_mrope_inplace followed by this call."""
     _need_gpu(q, k_new, v_new, k_cache, v_cache, pos_dev)
     if q.dtype != torch.bfloat16 or k_new.dtype != torch.bfloat16 or v_new.dtype != torch.bfloat16:
         raise ValueError("swa_forward is built for bf16")
@@ -492,20 +494,40 @@ def swa_forward(
     a.scaling = float(scaling)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     a.mma_dtype = mma_code(mma_dtype)
+    if rope is not None:
+        cos, sin, sec = _rope_args(rope, B, T, d)
+        a.rope_cos, a.rope_sin, a.rope_s0, a.rope_s1 = cos.data_ptr(), sin.data_ptr(), int(sec[0]), int(sec[1])
     _lib.check(lib.ivl_swa_fwd(ctypes.byref(a), _stream(q)))
     return o
 
 
+def _rope_args(rope, B: int, T: int, d: int):
+    cos, sin, sec = rope
+    if cos.dtype != torch.bfloat16 or not cos.is_contiguous():
+        cos = cos.to(torch.bfloat16).contiguous()
+    if sin.dtype != torch.bfloat16 or not sin.is_contiguous():
+        sin = sin.to(torch.bfloat16).contiguous()
+    if tuple(cos.shape) != (3, B, T, d) or tuple(sin.shape) != (3, B, T, d):
+        raise ValueError(f"rope cos/sin must be [3,B,T,d] = {(3, B, T, d)}; got {tuple(cos.shape)}")
+    return cos, sin, sec
+
+
 def swa_cache_append(k_new: torch.Tensor, v_new: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
-                     pos: int = 0, pos_dev: Optional[torch.Tensor] = None) -> None:
-    """Write the call's new tokens [B,T,Hkv,d] into the ring (slot (pos+t) % C); std:146-172."""
+                     pos: int = 0, pos_dev: Optional[torch.Tensor] = None, rope=None) -> None:
+    """Write the call's new tokens [B,T,Hkv,d] into the ring (slot (pos+t) % C); std:146-172.  `rope` as in
+    swa_forward: k_new is un-rotated and is rotated on the way into the ring."""
     _need_gpu(k_new, v_new, k_cache, v_cache)
     B, T, Hkv, d = k_new.shape
     if k_new.stride(-1) != 1 or v_new.stride() != k_new.stride():
         k_new, v_new = k_new.contiguous(), v_new.contiguous()
+    rc = rs = None
+    s0 = s1 = 0
+    if rope is not None:
+        rc, rs, sec = _rope_args(rope, B, T, d)
+        s0, s1 = int(sec[0]), int(sec[1])
     _lib.check(_lib.load().ivl_swa_cache_append(
         _p(k_new), _p(v_new), k_new.stride(0), k_new.stride(1), k_new.stride(2), _p(k_cache), _p(v_cache),
-        B, T, Hkv, d, k_cache.shape[2], int(pos), _p(pos_dev), _stream(k_new)))
+        B, T, Hkv, d, k_cache.shape[2], int(pos), _p(pos_dev), _p(rc), _p(rs), s0, s1, _stream(k_new)))
 
 
 def counter_add(counter: torch.Tensor, delta: int) -> None:

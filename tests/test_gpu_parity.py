@@ -295,6 +295,38 @@ def test_swa_fp8_prefill_calls_stay_bf16():
     assert r["o"] < 5e-3, r
 
 
+@pytest.mark.parametrize("B,T,seen,W", [(1, 256, 4500, 4096), (2, 70, 40, 96), (1, 1, 300, 96), (1, 300, 0, 4096), (1, 130, 100, 96)])
+def test_rope_fused_into_attention_and_append_is_bit_identical(B, T, seen, W):
+    """M-RoPE folded into the SWA kernel's Q load / new-key staging and into the ring append must equal
+    ivl_mrope_fwd followed by the plain kernels bit for bit (outputs and ring contents), across ring wrap, seam tiles,
+    decode and split-KV shapes."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d, C = 16, 2, 128, W - 1
+    g_ = torch.Generator(device=DEV).manual_seed(T + seen)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    q, k, v = rn(B, T, Hq, d), rn(B, T, Hkv, d), rn(B, T, Hkv, d)
+    kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
+    pos = torch.stack([torch.arange(seen, seen + T), torch.arange(T) // 3 + seen, torch.arange(T) % 7 + seen])[:, None, :]
+    pos = pos.expand(3, B, T).to(DEV)
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    from infinitevl_amd.modules import InfiniteVLRotaryEmbedding
+    cos, sin = InfiniteVLRotaryEmbedding(InfiniteVLTextConfig())(q, pos)
+    sec = [16, 24, 24]
+    pos_dev = torch.full((1,), seen, dtype=torch.int64, device=DEV)
+    # unfused
+    q1, k1 = q.clone(), k.clone()
+    ops.apply_mrope_inplace(q1, k1, cos, sin, sec)
+    kc1, vc1 = kc.clone(), vc.clone()
+    o1 = ops.swa_forward(q1, k1, v, window=W, scaling=d ** -0.5, k_cache=kc1, v_cache=vc1, pos_dev=pos_dev)
+    ops.swa_cache_append(k1, v, kc1, vc1, pos_dev=pos_dev)
+    # fused
+    kc2, vc2 = kc.clone(), vc.clone()
+    o2 = ops.swa_forward(q, k, v, window=W, scaling=d ** -0.5, k_cache=kc2, v_cache=vc2, pos_dev=pos_dev, rope=(cos, sin, sec))
+    ops.swa_cache_append(k, v, kc2, vc2, pos_dev=pos_dev, rope=(cos, sin, sec))
+    assert torch.equal(o1, o2)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+
+
 def test_swa_reference_vectors_d128():
     """Row S3 pinned DIRECTLY to the reference: outputs of the reference's eager_attention_forward (fp32, band mask from
     the S2 predicate) at the kernel's head shape d = 128 -- GQA group 8 and 16-over-2 heads, empty / partly / fully cached,
