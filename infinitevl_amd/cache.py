@@ -200,15 +200,17 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
 
     # ---- state hand-off (sequence-parallel prefill) ------------------------------------
     def carried_tensors(self):
-        """Device tensors that fully define what the NEXT tokens of the sequence need from this layer: the ring
-        (last W-1 post-RoPE keys / values in slot order) and its position counter."""
-        return [t for t in (self._buf_keys, self._buf_values, self._pos_dev) if t is not None]
+        """Device tensors that define what the NEXT tokens of the sequence need from this layer: the ring (last W-1
+        post-RoPE keys / values in slot order).  The position counter is not carried (inside an aggregate cache it is
+        shared by all sliding layers and advanced once per forward): import_carried() sets it from `seen_tokens`."""
+        return [t for t in (self._buf_keys, self._buf_values) if t is not None]
 
     def import_carried(self, seen_tokens: int) -> None:
-        """Host-side counters after carried_tensors() were overwritten with the state of a sequence prefix of
-        `seen_tokens` tokens (the device counter arrived with the tensors)."""
+        """Counters (host and device) after carried_tensors() were overwritten with the state of a sequence prefix of
+        `seen_tokens` tokens."""
         self.size = int(min(self.capacity, seen_tokens))
         self.cumulative_length = int(seen_tokens)
+        self._pos_dev.fill_(int(seen_tokens))
 
     def clone(self) -> "StaticSlidingWindowLayerPrealloc":
         """Deep copy (what the demo's clone_inference_cache does, demo:123-146)."""

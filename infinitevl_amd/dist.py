@@ -109,6 +109,26 @@ def recv_tensors_(tensors: Sequence[torch.Tensor], src: int) -> None:
             dist.recv(t, src)
 
 
+class _Pending:
+    """One layer's hand-off in flight: ONE batch_isend_irecv for all its tensors (a single RCCL group call per hop
+    instead of one blocking send/recv per tensor)."""
+
+    def __init__(self, tensors: Sequence[torch.Tensor], peer: int, recv: bool):
+        self.tensors, self.recv = list(tensors), recv
+        self.stage = [torch.empty(t.shape, dtype=t.dtype, device="cpu") if recv else t.cpu()
+                      for t in self.tensors] if any(_p2p_stage_through_host(t) for t in self.tensors) else None
+        bufs = self.stage if self.stage is not None else self.tensors
+        op = dist.irecv if recv else dist.isend
+        self.reqs = dist.batch_isend_irecv([dist.P2POp(op, b_, peer) for b_ in bufs]) if bufs else []
+
+    def wait(self) -> None:
+        for r in self.reqs:
+            r.wait()
+        if self.recv and self.stage is not None:
+            for t, b_ in zip(self.tensors, self.stage):
+                t.copy_(b_)
+
+
 def segment_bounds(total_tokens: int, rank: int, world: int, multiple: int = 64) -> Tuple[int, int]:
     """[first, last) token range of segment `rank`: equal segments rounded up to `multiple` tokens (the GDN chunk
     length, so that a segment boundary is a chunk boundary); trailing ranks may get a short or empty segment."""
@@ -134,22 +154,35 @@ def sequence_parallel_prefill(model: Callable, inputs_embeds: torch.Tensor, cach
         world = dist.get_world_size() if dist.is_initialized() else 1
     B, T = inputs_embeds.shape[0], inputs_embeds.shape[1]
     has_prev, has_next = rank > 0 and first_token > 0, rank + 1 < world
+    n_layers = len(cache.layers)
+    recvs, sends = {}, []
+
+    def post_recv(i: int) -> None:
+        if has_prev and i < n_layers and i not in recvs:
+            recvs[i] = _Pending(cache.layers[i].carried_tensors(), rank - 1, recv=True)
 
     def before(i: int) -> None:
+        # layer i's state was requested one layer earlier (its tensors are not touched until now), so the transfer ran
+        # under layer i-1's mixer and MLP; layer i+1's is requested now and runs under this layer's
         if has_prev:
-            layer = cache.layers[i]
-            recv_tensors_(layer.carried_tensors(), rank - 1)
-            layer.import_carried(first_token)
+            post_recv(i)
+            recvs.pop(i).wait()
+            cache.layers[i].import_carried(first_token)
+            post_recv(i + 1)
 
     def after(i: int) -> None:
-        if has_next:
-            send_tensors(cache.layers[i].carried_tensors(), rank + 1)
+        if has_next:                              # non-blocking: the MLP of this layer overlaps the transfer
+            sends.append(_Pending(cache.layers[i].carried_tensors(), rank + 1, recv=False))
 
     if T == 0:                                   # nothing to compute: pass every layer's state through
-        for i in range(len(cache.layers)):
+        for i in range(n_layers):
             before(i)
             after(i)
-        return None, None
-    pos = torch.arange(first_token, first_token + T, device=inputs_embeds.device)[None, None, :].expand(3, B, T)
-    return model(inputs_embeds=inputs_embeds, position_ids=pos.contiguous(), past_key_values=cache,
-                 logits_to_keep=logits_to_keep, layer_hooks=(before, after))
+        out = (None, None)
+    else:
+        pos = torch.arange(first_token, first_token + T, device=inputs_embeds.device)[None, None, :].expand(3, B, T)
+        out = model(inputs_embeds=inputs_embeds, position_ids=pos.contiguous(), past_key_values=cache,
+                    logits_to_keep=logits_to_keep, layer_hooks=(before, after))
+    for p_ in sends:
+        p_.wait()
+    return out

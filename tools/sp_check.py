@@ -21,8 +21,8 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     heads, hidden, window = 2, 256, 96
-    lt = ["sliding_attention" if i % 4 == 0 else "linear_attention" for i in range(4)]
-    cfg = InfiniteVLTextConfig(vocab_size=512, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=4,
+    lt = ["sliding_attention" if i % 4 == 0 else "linear_attention" for i in range(8)]      # two sliding layers: shared counter
+    cfg = InfiniteVLTextConfig(vocab_size=512, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=8,
                                num_attention_heads=heads, num_key_value_heads=1, head_dim=128, sliding_window=window,
                                layer_types=lt, num_linear_heads=heads, num_linear_key_value_heads=heads,
                                linear_head_dim=128, rope_theta=1e6)
