@@ -358,16 +358,19 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   }
   __syncthreads();                                   // B3: k_hat / q_hat are dead from here on
   IVL_T(tp3a);
-  if (wave_u >= 4) {                                 // bf16(beta v) row-major over the dead region (read after B7)
+  // bf16(beta v) row-major over the dead region (read after B7): waves 4-7 write one half of their rows here, beside the
+  // short level 1, and the other half beside level 2 -- neither phase waits for the ~200 VALU instructions of all eight rows
+  auto write_beta_v = [&](int i0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = i0; i < i0 + 4; ++i) {
       const int row = vr + 8 * i;
       const u32x4 vv = vraw[i];
       const float bt = s_beta[row];
       *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
           pack8(bflo(vv.x) * bt, bfhi(vv.x) * bt, bflo(vv.y) * bt, bfhi(vv.y) * bt, bflo(vv.z) * bt, bfhi(vv.z) * bt, bflo(vv.w) * bt, bfhi(vv.w) * bt);
     }
-  }
+  };
+  if (wave_u >= 4) write_beta_v(0);
   // level 1: X[hb][lb] = -D_hb (L[hb][lb] D_lb) for the block pairs (1,0) and (3,2); the intermediate product stays in
   //          the accumulator registers: with the contraction order k = 4g + s (lane group g, instruction s) register s
   //          of a 16x16x4 result IS the B operand of instruction s of the next product.
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   //          P = T[0:32,0:32] and Q = T[32:64,32:64] are lower triangular: P[0][1] = Q[0][1] = 0.
   f32x4 Z = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ib = (wave_u >> 1) & 1, jb = wave_u & 1;
+  if (wave_u >= 4) write_beta_v(4);
   if (wave_u < 4) {
     f32x4 M[2];
 #pragma unroll
