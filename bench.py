@@ -235,9 +235,9 @@ def pmc_traffic(kernel_name, chunk, window):
         return None
     k = json.load(open(files[-1]))["kernels"]
     want = {
-        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel", 32768), ("ivl::gdn_chunk_scan_kernel<2>", 49152)],
+        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
         "swa_prefill": [("ivl::swa_fwd_kernel<false,", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
-        "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 36864)],
+        "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
         "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],
         "gdn_recurrent(decode)": [("ivl::gdn_recurrent_kernel", 32768)],

@@ -6,7 +6,7 @@
 #   SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE   extra LDS cycles lost to bank conflicts / all LDS-array cycles
 # -> gpurun_out/profiles/<tag>_pmc_mfma_lds.json (per kernel and grid: mean counter values per launch + derived ratios)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p $OUT
@@ -33,11 +33,10 @@ for c in ctrs:
         agg[(short, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     data[c] = agg
 out = {"note": "mean counter value per launch, summed over the device as rocprofv3 reports it.  "
-               "SQ_VALU_MFMA_BUSY_CYCLES = 32 per v_mfma_f32_32x32x16_bf16 / 16x16x4_f32, 16 per 16x16x32_bf16 (checked against "
-               "the instruction counts of gdn_chunk_prepare / scan: 64 x 224 x 32 and 128 x 4 x 1792 exactly).  "
+               "SQ_VALU_MFMA_BUSY_CYCLES = 32 per v_mfma_f32_32x32x16_bf16 / 16x16x4_f32, 16 per 16x16x32 (bf16 or fp8).  "
                "GRBM_GUI_ACTIVE = 8 XCDs x active cycles + a ~2e5 profiling offset: not used for ratios; MFMA utilisation = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz) with the duration from "
-               "r01_bench_kernel_stats.csv / bench.py.  lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE", "kernels": {}}
+               "<tag>_bench_kernel_by_grid.csv / bench.py.  lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE", "kernels": {}}
 keys = set()
 for c in ctrs:
     keys |= set(data[c])

@@ -6,7 +6,7 @@
 #      MI355X_MICROARCH.md prescribes; calibrated on add_rmsnorm whose byte count is known exactly)
 # Copy the files you want judged into profiles/ afterwards.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p $OUT
@@ -26,7 +26,11 @@ for f in glob.glob("/tmp/prof_bench/**/*kernel_trace.csv", recursive=True):
 agg = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    agg[(name, int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    def dim(prefix):
+        if prefix in r:
+            return int(r[prefix])
+        return int(r[prefix + "_X"]) * int(r[prefix + "_Y"]) * int(r[prefix + "_Z"])
+    agg[(name, dim("Grid_Size"), dim("Workgroup_Size"))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open("$OUT/${TAG}_bench_kernel_by_grid.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "grid_threads", "workgroup_threads", "launches", "avg_ns", "min_ns", "max_ns", "total_ns"])
