@@ -655,6 +655,9 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
   constexpr int IMG_BYTES = Img<F8>::BYTES, IMG_U = Img<F8>::U, BLK = R::BLK;
 
   IVL_T(ts0);
+#ifdef IVL_TRACE
+  const long long rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   IVL_TVAR(t_bar); IVL_TVAR(t_bar2); IVL_TVAR(t_h1); IVL_TVAR(t_h2); IVL_TVAR(t_sb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -850,6 +853,9 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
   }
   IVL_T(ts2);
   IVL_TOUT(16, ts0); IVL_TOUT(17, t_bar); IVL_TOUT(18, t_h1); IVL_TOUT(19, t_h2); IVL_TOUT(20, ts1 - ts0); IVL_TOUT(21, ts2 - ts1);
+#ifdef IVL_TRACE
+  IVL_TOUT(25, (long long)__builtin_amdgcn_s_memrealtime() - rt0);
+#endif
   IVL_TOUT(22, ts2); IVL_TOUT(23, t_bar2); IVL_TOUT(24, t_sb);
 }
 

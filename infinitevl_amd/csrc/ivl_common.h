@@ -81,7 +81,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
     if (tb_ != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
       tb_[slot] = (long long)(value);                                                              \
   } while (0)
+#define IVL_TOUT_AT(tid, slot, value)                                                              \
+  do {                                                                                             \
+    long long* tb_ = ivl_trace_buf;                                                                \
+    if (tb_ != nullptr && threadIdx.x == (tid) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+      tb_[slot] = (long long)(value);                                                              \
+  } while (0)
 #else
+#define IVL_TOUT_AT(tid, slot, value) ((void)0)
 #define IVL_TRACE_DECL(unit)
 #define IVL_T(name) ((void)0)
 #define IVL_TVAR(name) ((void)0)
