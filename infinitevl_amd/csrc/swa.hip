@@ -13,6 +13,7 @@
 //   lo = max(0, n_prev + t - W + 1) .. hi = n_prev + t.
 // Long key ranges are optionally split across workgroups (flash-decoding); a combine kernel merges.
 #include "ivl_common.h"
+#include <type_traits>
 
 namespace ivl {
 
@@ -350,7 +351,10 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
             sacc[qg][mt][r] = vis ? sacc[qg][mt][r] : -INFINITY;
           }
       }
-      float rmax = vmax3(sacc[qg][0][0], sacc[qg][0][1], sacc[qg][0][2]);
+      // the FIRST reader of the MFMA results must be an instruction the compiler sees: its hazard recognizer inserts the
+      // wait states between an MFMA and a dependent VALU read, but does not look inside inline asm (on an interior tile
+      // the asm v_max3 would otherwise follow the last MFMA directly and read the accumulators too early)
+      float rmax = vmax2(__builtin_fmaxf(sacc[qg][0][0], sacc[qg][0][1]), sacc[qg][0][2]);
       rmax = vmax3(rmax, sacc[qg][0][3], sacc[qg][1][0]);
       rmax = vmax3(rmax, sacc[qg][1][1], sacc[qg][1][2]);
       rmax = vmax3(rmax, sacc[qg][1][3], sacc[qg][2][0]);
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 //               keeps the LDS array busy 768 clk per tile for 544 clk of MFMA per SIMD; 128 rows at 32 per wave give the
 //               same parallelism (workgroups per call) as 16-row waves with half the LDS bytes per MFMA, and the two
 //               waves of one SIMD come from the same workgroup (one barrier per tile, K/V double-buffered in LDS).
-//   S^T = K Q^T : A = K rows (ds_read_b128, 16-byte pieces XOR-swizzled by the row), B = Q^T in registers; lane
+//   S^T = K Q^T : A = K rows (ds_read_b128, rows padded to 272 B), B = Q^T in registers; lane
 //               (row = l & 31, hi = l >> 5) receives the scores of keys (r & 3) + 8 (r >> 2) + 4 hi, r = 0..15.
 //   O^T = V^T P^T : the MFMA k-slot 8 hi + j of key step ks carries key 16 ks + 8 (j >> 2) + 4 hi + (j & 3): exactly
 //               the order of the lane's own score registers r = 8 ks + j, so P^T is packed in place (no lane exchange);
@@ -468,20 +472,25 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 //   epilogue  : key-half 1 parks (m, l, O) in LDS, key-half 0 merges and writes the finished rows back, then all 512
 //               threads store whole rows (256 B of bf16 or 512 B of fp32 partials per row, coalesced).
 constexpr int PF_QT = 128;
+constexpr int PF_THREADS = 768;                                  // 8 compute wavefronts + 4 loader wavefronts (3 per SIMD)
 constexpr int PF_VSTRIDE = 320;
-constexpr int PF_K_BYTES = SWA_KT * SWA_KSTRIDE;                 // 16 KB per K stage (two of them)
-constexpr int PF_V_BYTES = SWA_KT * PF_VSTRIDE;                  // 20 KB per V stage (three of them)
-constexpr int PF_V_OFF = 2 * PF_K_BYTES;
-constexpr int PF_LDS_BYTES = PF_V_OFF + 3 * PF_V_BYTES;          // 92 KB
+constexpr int PF_KSTRIDE = 272;                                  // K rows padded by 16 B: the 32-row ds_read_b128 pattern of
+                                                                 // the 32x32x16 A fragment is conflict-free, offsets are immediates
+constexpr int PF_STAGES = 3;                                     // the loaders run up to two tiles ahead of the compute waves
+constexpr int PF_K_BYTES = SWA_KT * PF_KSTRIDE;                  // 17 KB per K stage
+constexpr int PF_V_BYTES = SWA_KT * PF_VSTRIDE;                  // 20 KB per V stage
+constexpr int PF_V_OFF = PF_STAGES * PF_K_BYTES;
+constexpr int PF_LDS_BYTES = PF_V_OFF + PF_STAGES * PF_V_BYTES;  // 111 KB
 constexpr int PF_OSTRIDE = 528;                                  // bytes per merged fp32 row (512 + 16: bank shift per row)
 constexpr int PF_ML_OFF = 4 * 32 * PF_OSTRIDE;                   // (m, l) pairs behind the four 32-row images
 static_assert(PF_ML_OFF + 128 * 8 <= PF_LDS_BYTES, "merge image must fit the K/V stages");
 
-__global__ __launch_bounds__(512, 1) void swa_prefill_kernel(SwaParams p) {
+__global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[PF_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
-  const int rg = wave & 3, kh = wave >> 2;
+  const bool loader = wave >= 8;
+  const int rg = wave & 3, kh = (wave >> 2) & 1;
   // same XCD-aware block order as swa_fwd_kernel: logical ids (b, split, head, q-tile), heads of one kv group adjacent
   int bx, rest;
   {
@@ -511,15 +520,6 @@ __global__ __launch_bounds__(512, 1) void swa_prefill_kernel(SwaParams p) {
   const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;
 
   const int tile_row0 = bx * PF_QT;
-  const int row = tile_row0 + 32 * rg + l31;
-  const bool row_ok = row < p.T;
-  const int band_hi = n_prev + row;
-  const int band_lo = p.W > 0 ? max(0, n_prev + row - p.W + 1) : 0;
-  // band extremes of this wave's 32 rows (lo / hi are monotone in the row)
-  const int wr0 = tile_row0 + 32 * rg, wr1 = max(min(wr0 + 31, p.T - 1), wr0);
-  const int w_hi_min = n_prev + wr0, w_hi_max = n_prev + wr1;
-  const int w_lo_min = p.W > 0 ? max(0, n_prev + wr0 - p.W + 1) : 0;
-  const int w_lo_max = p.W > 0 ? max(0, n_prev + wr1 - p.W + 1) : 0;
   // workgroup key-tile range
   const int last_row = min(tile_row0 + PF_QT, p.T) - 1;
   const int lo_min = p.W > 0 ? max(0, n_prev + tile_row0 - p.W + 1) : 0;
@@ -527,338 +527,427 @@ __global__ __launch_bounds__(512, 1) void swa_prefill_kernel(SwaParams p) {
   const int per = (kt1 - kt0 + p.nsplit - 1) / p.nsplit;
   const int kt_begin = kt0 + split * per;
   const int kt_end = min(kt1, kt_begin + per);
+  const int n = kt_end - kt_begin;            // workgroup-uniform
 
-  // ---- Q^T fragments (B operand): lane = query row, d = 16 kd + 8 hi .. +7 -----------------------------------------
-  u32x4 qf[8];
-  {
-    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(row, p.T - 1) * p.q_st + (long long)hq * p.q_sh;
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qp + 16 * kd + 8 * hi5);
-  }
-  const long long rplane = (long long)p.B * p.T * SWA_D;
-  if (p.rcos != nullptr) {
-    const long long row_off = ((long long)b * p.T + min(row, p.T - 1)) * SWA_D;
-#pragma unroll
-    for (int kd = 0; kd < 4; ++kd) rope_pair(qf[kd], qf[kd + 4], p.rcos, p.rsin, rplane, row_off, 16 * kd + 8 * hi5, p.rs0, p.rs1);
-  }
-  if (!row_ok) {
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) qf[kd] = u32x4{0u, 0u, 0u, 0u};
-  }
-  float m_run = -INFINITY, l_run = 0.f;     // l_run: this LANE's part of the row sum (its 16 keys of every tile)
-  f32x16 oacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-
-  // ---- staging: thread -> rows (tid >> 4) + 32 i, 16-byte chunk tid & 15; K and V of a tile travel separately -------
-  // Addresses = workgroup-uniform base (scalar registers) + 32-bit element offset per thread.
-  const int srow = tid >> 4, schunk = tid & 15;
-  u32x4 kreg[2], vreg[2];
-  const long long ring_off = p.C > 0 ? (((long long)b * p.Hkv + hk) * p.C) * SWA_D : 0;
-  const bf16_t* const kb_ring = p.C > 0 ? p.k_cache + ring_off : p.k_new;
-  const bf16_t* const vb_ring = p.C > 0 ? p.v_cache + ring_off : p.v_new;
-  const long long new_off = (long long)b * p.kn_sb + (long long)hk * p.kn_sh;
-  const bf16_t* const kb_new = p.k_new + new_off;
-  const bf16_t* const vb_new = p.v_new + new_off;
-  const unsigned int kn_st32 = (unsigned int)p.kn_st;
-  const unsigned int ch_off = schunk * 8;
-  const bf16_t* const rope_cos = p.rcos + (long long)b * p.T * SWA_D;     // row jn of plane s: + s * rplane + jn * 128
-  const bf16_t* const rope_sin = p.rsin + (long long)b * p.T * SWA_D;
-  auto rope_new_key = [&](u32x4& kv, int jn) {
-    const u32x4 part = *(const u32x4*)(kb_new + ((unsigned int)jn * kn_st32 + (schunk ^ 8) * 8));
-    u32x4 lo = schunk < 8 ? kv : part, hi = schunk < 8 ? part : kv;
-    rope_pair(lo, hi, rope_cos, rope_sin, rplane, (long long)jn * SWA_D, (schunk & 7) * 8, p.rs0, p.rs1);
-    kv = schunk < 8 ? lo : hi;
-  };
-  // K and V rows of the 64-key tile kt into kreg / vreg (same rows, same offsets)
-  auto load_tile = [&](int kt) {
-    const int j0 = kt * SWA_KT;
-    const int slot0 = s0 + j0;
-    if (j0 + SWA_KT <= n_ring && (slot0 + SWA_KT <= p.C || slot0 >= p.C)) {       // 64 consecutive ring slots
-      const unsigned int off = (unsigned int)((slot0 >= p.C ? slot0 - p.C : slot0) + srow) * SWA_D + ch_off;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        kreg[i] = *(const u32x4*)(kb_ring + (off + 32 * i * SWA_D));
-        vreg[i] = *(const u32x4*)(vb_ring + (off + 32 * i * SWA_D));
-      }
-      return;
-    }
-    if (j0 >= n_ring && j0 + SWA_KT <= S) {                                        // 64 keys of this call
-      const unsigned int off = (unsigned int)(j0 - n_ring + srow) * kn_st32 + ch_off;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        kreg[i] = *(const u32x4*)(kb_new + (off + 32 * i * kn_st32));
-        vreg[i] = *(const u32x4*)(vb_new + (off + 32 * i * kn_st32));
-      }
-    } else {
-      // ring wrap, ring / new seam, tail: every row loads from BOTH sources at a clamped offset and selects
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int j = j0 + srow + 32 * i;
-        const int jc = min(j, S - 1);
-        int slot = s0 + min(jc, max(n_ring - 1, 0));
-        slot = slot >= p.C ? slot - p.C : slot;
-        const unsigned int o_ring = (unsigned int)slot * SWA_D + ch_off;
-        const unsigned int o_new = (unsigned int)max(jc - n_ring, 0) * kn_st32 + ch_off;
-        const u32x4 ka = *(const u32x4*)(kb_ring + o_ring), kc = *(const u32x4*)(kb_new + o_new);
-        const u32x4 va = *(const u32x4*)(vb_ring + o_ring), vc = *(const u32x4*)(vb_new + o_new);
-        kreg[i] = jc < n_ring ? ka : kc;
-        vreg[i] = jc < n_ring ? va : vc;
-        if (j >= S) {
-          kreg[i] = u32x4{0u, 0u, 0u, 0u};
-          vreg[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-      }
-    }
-    if (p.rcos != nullptr) {            // the tile holds keys of this call: rotate them
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int jn = min(j0 + srow + 32 * i, S - 1) - n_ring;
-        if (jn >= 0) rope_new_key(kreg[i], jn);
-      }
-    }
-  };
-  auto store_tile = [&](int kbuf, int vbuf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow + 32 * i;
-      *(u32x4*)(smem + kbuf * PF_K_BYTES + r * SWA_KSTRIDE + ((schunk ^ (r & 15)) << 4)) = kreg[i];
-      *(u32x4*)(smem + PF_V_OFF + vbuf * PF_V_BYTES + r * PF_VSTRIDE + schunk * 16) = vreg[i];
-    }
-  };
-  // tile barrier: LDS stores are visible behind it, global loads stay in flight across it, nothing is scheduled across it
-  auto tile_barrier = [&]() {
+  // barrier between two segments of the tile loop: LDS stores of the segment are visible behind it; global loads stay in
+  // flight across it (no vmcnt wait), and no instruction is scheduled across it
+  auto seg_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const float sc = p.scaling * LOG2E;
-  const int n = kt_end - kt_begin;            // workgroup-uniform
-  // per-lane LDS offsets: K fragment row (32 kh + l31), V^T fragment block rows / columns
-  const int k_row_off = (32 * kh + l31) * SWA_KSTRIDE;
-  const int v_off = PF_V_OFF + (32 * kh + 4 * hi5 + (l15 >> 2)) * PF_VSTRIDE + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
-  auto is_dead = [&](int kt) {                // no row of the wave sees any of its 32 keys of tile kt
-    const int kbeg = kt * SWA_KT + 32 * kh;
-    return kbeg > w_hi_max || kbeg + 31 < w_lo_min;
-  };
+  // Segments sigma = 0 .. 2n, each closed by a barrier (after one barrier that publishes tile 0):
+  //   key half 0 :  A(t) = K fragments, S = K Q^T, row max      at sigma = 2t       B(t) = V^T fragments, exponentials,
+  //   key half 1 :  the same code ONE SEGMENT LATER (2t + 1, 2t + 2)                        O^T += V^T P^T   at 2t + 1
+  //   loaders    :  sigma = 2t: K(t+1) -> LDS over K(t-1) (last read at 2t - 1), loads of K(t+3) put in flight
+  //                 sigma = 2t + 1: V(t+1) -> LDS over V(t-1) (last read at 2t), loads of V(t+3) put in flight
+  // so the MFMA chain of one compute wave always faces the VALU-bound softmax of its SIMD partner, and no compute wave
+  // ever waits for a global load or issues an LDS store inside the loop.
+  if (loader) {
+    // ---- loader wavefronts: waves 8, 9 stage K, waves 10, 11 stage V, by LDS-DMA (global_load_lds_dwordx4: 1 KB of LDS per
+    //      wave-instruction, lane l -> bytes 16 l .. 16 l + 15 of the chunk).  The padded images are covered chunk by chunk:
+    //      16-byte piece q = 64 chunk + lane of the K image is (row q / 17, column q % 17), of the V image (q / 20, q % 20);
+    //      column 16.. is padding (the lane fetches a harmless address).  No data registers, no ds_write, and nothing for
+    //      the compiler to wait on: completion is a counted s_waitcnt vmcnt before the barrier that publishes the tile. ------
+   auto loader_body = [&](auto is_k_tag) {
+    constexpr bool is_k = decltype(is_k_tag)::value;
+    constexpr int PPR = is_k ? PF_KSTRIDE / 16 : PF_VSTRIDE / 16;        // 16-byte pieces per image row (17 | 20)
+    const int chunk0 = is_k ? (wave == 8 ? 0 : 9) : (wave == 10 ? 0 : 10);
+    const int nch = is_k ? (wave == 8 ? 9 : 8) : 10;                      // chunks of this wave
+    const long long ring_off = p.C > 0 ? (((long long)b * p.Hkv + hk) * p.C) * SWA_D : 0;
+    const long long new_off = (long long)b * p.kn_sb + (long long)hk * p.kn_sh;
+    const bf16_t* const b_ring = p.C > 0 ? (is_k ? p.k_cache : p.v_cache) + ring_off : (is_k ? p.k_new : p.v_new);
+    const bf16_t* const b_new = (is_k ? p.k_new : p.v_new) + new_off;
+    const unsigned int kn_st32 = (unsigned int)p.kn_st;
+    const long long rplane = (long long)p.B * p.T * SWA_D;
+    const bf16_t* const rope_cos = p.rcos + (long long)b * p.T * SWA_D;
+    const bf16_t* const rope_sin = p.rsin + (long long)b * p.T * SWA_D;
+    // per-lane byte offset of the chunk's piece in a 64-row tile (recomputed per instruction: a table of them ends up in scratch)
+    auto piece_off = [&](int c, bool ring) -> unsigned int {
+      const int q = 64 * (chunk0 + c) + lane;
+      const int r = q / PPR, col = q % PPR;
+      const bool pad = col >= 16 || r >= SWA_KT;
+      return pad ? 0u : (ring ? (unsigned int)(r * SWA_D * 2 + col * 16) : (unsigned int)r * kn_st32 * 2 + col * 16);
+    };
 
-  u32x4 fr[8], pf[2];       // K fragments and V^T fragments time-share one register block
-  float m_use = 0.f, alpha = 1.f;
-  bool need = false;
-  f32x16 sacc;
-  auto row_max = [&](int kt) {      // band mask, running max, rescale factor
-    const int kbeg = kt * SWA_KT + 32 * kh;
-    const bool interior = kbeg >= w_lo_max && kbeg + 31 <= w_hi_min;
-    if (!interior) {
-      const int jb = kbeg + 4 * hi5;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = jb + (r & 3) + 8 * (r >> 2);
-        const bool vis = row_ok && j >= band_lo && j <= band_hi;
-        sacc[r] = vis ? sacc[r] : -INFINITY;
+    const unsigned int img0 = is_k ? 0u : (unsigned int)PF_V_OFF;
+    const unsigned int img_bytes = is_k ? (unsigned int)PF_K_BYTES : (unsigned int)PF_V_BYTES;
+    // Tile kinds (wave-uniform): 64 consecutive ring slots | 64 already-rotated keys of this call -> DMA; anything else
+    // (ring wrap, ring / new seam, tail, un-rotated new keys) -> loaded through registers, fixed up and stored
+    // synchronously (slow_store): the loaders run up to two tiles ahead of the compute waves, which absorbs it.
+    auto tile_kind = [&](int kt, bool& ring_fast) -> bool {
+      const int j0 = kt * SWA_KT, slot0 = s0 + j0;
+      ring_fast = j0 + SWA_KT <= n_ring && (slot0 + SWA_KT <= p.C || slot0 >= p.C);
+      const bool new_fast = j0 >= n_ring && j0 + SWA_KT <= S && !(is_k && p.rcos != nullptr);
+      return ring_fast || new_fast;
+    };
+    auto dma_tile = [&](int kt, int st, bool ring_fast, int c_lo, int c_hi) {
+      const int j0 = kt * SWA_KT, slot0 = s0 + j0;
+      const unsigned long long base_u = ring_fast
+          ? (unsigned long long)(b_ring + (long long)(slot0 >= p.C ? slot0 - p.C : slot0) * SWA_D)
+          : (unsigned long long)(b_new + (long long)(j0 - n_ring) * p.kn_st);
+      const unsigned char* const base = (const unsigned char*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(base_u >> 32)) << 32) |
+                                                               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)base_u));
+      const unsigned int lds0 = (unsigned int)(size_t)smem + img0 + (unsigned int)st * img_bytes + (unsigned int)chunk0 * 1024u;
+#define PF_DMA(c)                                                                                                         \
+      if (c >= c_lo && c < c_hi) {                                                                                                      \
+        unsigned int keep;                                                                                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"       \
+                     : "=&s"(keep) : "v"(piece_off(c, ring_fast)), "s"(lds0 + 1024u * c), "s"(base) : "memory");           \
       }
+      PF_DMA(0) PF_DMA(1) PF_DMA(2) PF_DMA(3) PF_DMA(4) PF_DMA(5) PF_DMA(6) PF_DMA(7) PF_DMA(8) PF_DMA(9)
+#undef PF_DMA
+    };
+    // slow tile: clamped per-row loads from both sources, zero rows past the end, rope of the call's keys, LDS stores.
+    // 128 lanes: K: lane -> rows (L >> 3) + 16 i (i < 4), the chunk pair (c, c + 8) (both halves of a rope pair);
+    // V: rows (L >> 4) + 8 i (i < 8), chunk L & 15.
+    const int L = (tid - 512) & 127;
+    auto slow_store = [&](int kt, int st) {
+      const int kc = L & 7, row0 = is_k ? L >> 3 : L >> 4, RS = is_k ? 16 : 8;
+      const unsigned int ch_off = is_k ? kc * 8 : (L & 15) * 8;
+      const int j0 = kt * SWA_KT;
+      u32x4 r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ri = is_k ? i >> 1 : i;                         // row index of this piece
+        const int j = j0 + row0 + RS * ri;
+        const int jc = min(j, S - 1);
+        int slot = s0 + min(jc, max(n_ring - 1, 0));
+        slot = slot >= p.C ? slot - p.C : slot;
+        const unsigned int co = ch_off + (is_k && (i & 1) ? 64u : 0u);
+        const u32x4 a0 = *(const u32x4*)(b_ring + ((unsigned int)slot * SWA_D + co));
+        const u32x4 c0 = *(const u32x4*)(b_new + ((unsigned int)max(jc - n_ring, 0) * kn_st32 + co));
+        r[i] = j < S ? (jc < n_ring ? a0 : c0) : u32x4{0u, 0u, 0u, 0u};
+      }
+      if (is_k && p.rcos != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int jn = min(j0 + row0 + RS * i, S - 1) - n_ring;
+          if (jn >= 0) rope_pair(r[2 * i], r[2 * i + 1], rope_cos, rope_sin, rplane, (long long)jn * SWA_D, kc * 8, p.rs0, p.rs1);
+          if (i & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (is_k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned char* rowp = smem + st * PF_K_BYTES + (row0 + 16 * i) * PF_KSTRIDE + kc * 16;
+          *(u32x4*)rowp = r[2 * i];
+          *(u32x4*)(rowp + 128) = r[2 * i + 1];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          *(u32x4*)(smem + PF_V_OFF + st * PF_V_BYTES + (row0 + 8 * i) * PF_VSTRIDE + (L & 15) * 16) = r[i];
+      }
+    };
+    // tile i of the workgroup's range into stage i % 3, in two parts (part 0: the first PF_H1 DMA instructions, or the whole
+    // tile when it takes the register path; part 1: the rest); returns true when part 0 issued DMA instructions
+    constexpr int PF_H1 = 5;
+    auto fetch = [&](int i, int part) -> bool {
+      if (i >= n) return false;
+      bool rf;
+      const int st = i % PF_STAGES;
+      if (tile_kind(kt_begin + i, rf)) {
+        if (part == 0) dma_tile(kt_begin + i, st, rf, 0, PF_H1);
+        else dma_tile(kt_begin + i, st, rf, PF_H1, nch);
+        return true;
+      }
+      if (part == 0) slow_store(kt_begin + i, st);
+      return false;
+    };
+    // everything issued before part 0 of the newest tile (`newest_dma`: its PF_H1 instructions may stay in flight) has landed
+    auto wait_older = [&](bool newest_dma) {
+      if (!newest_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    };
+    static_assert(PF_H1 == 5, "wait_older counts PF_H1 instructions");
+    IVL_TVAR(tl_k); IVL_TVAR(tl_kw); IVL_TVAR(tl_v); IVL_TVAR(tl_vw);
+    fetch(0, 0); fetch(0, 1);
+    fetch(1, 0); fetch(1, 1);
+    bool newest = false;
+    wait_older(false);
+    seg_barrier();                              // tiles 0 and 1 are in LDS: the compute waves start
+    // K(i): stage free from segment 2i - 4, complete before barrier 2i - 1: issued in segments 2i - 4 | 2i - 3, waited for in 2i - 1.
+    // V(i): free from 2i - 3, complete before barrier 2i: issued in segments 2i - 3 | 2i - 2, waited for in 2i.
+#pragma nounroll
+    for (int j = 0; j < n; ++j) {
+      IVL_T(tl0);
+      if (is_k) {
+        newest = fetch(j + 2, 0);               // K(j+2) over K(j-1), last read before barrier 2j - 1
+      } else {
+        wait_older(newest);                     // V(j) has landed (part 0 of V(j+1) may still fly)
+        if (j >= 1) fetch(j + 1, 1);
+      }
+      IVL_T(tl1);
+      seg_barrier();                            // sigma = 2j
+      IVL_T(tl2);
+      if (is_k) {
+        wait_older(newest);                     // K(j+1) has landed
+        fetch(j + 2, 1);
+      } else {
+        newest = fetch(j + 2, 0);               // V(j+2) over V(j-1), last read before barrier 2j
+      }
+      IVL_T(tl3);
+      seg_barrier();                            // sigma = 2j + 1
+      IVL_T(tl4);
+      IVL_TACC(tl_k, tl1, tl0); IVL_TACC(tl_kw, tl2, tl1); IVL_TACC(tl_v, tl3, tl2); IVL_TACC(tl_vw, tl4, tl3);
     }
-    float rmax = vmax3(sacc[0], sacc[1], sacc[2]);
-    rmax = vmax3(rmax, sacc[3], sacc[4]);
-    rmax = vmax3(rmax, sacc[5], sacc[6]);
-    rmax = vmax3(rmax, sacc[7], sacc[8]);
-    rmax = vmax3(rmax, sacc[9], sacc[10]);
-    rmax = vmax3(rmax, sacc[11], sacc[12]);
-    rmax = vmax3(rmax, sacc[13], sacc[14]);
-    rmax = vmax2(rmax, sacc[15]);
-    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
-    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
-    const float m_new = vmax2(m_run, rmax);
-    m_use = m_new == -INFINITY ? 0.f : m_new;
-    need = __any(m_new > m_run);
-    alpha = __builtin_amdgcn_exp2f(m_run - m_use);     // 1 for a row whose maximum did not move, 0 for a first tile
-    m_run = m_new;
-  };
-  auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
-    if (need) {                        // some row's running maximum moved: rescale (exact)
+    seg_barrier();                              // sigma = 2n
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IVL_TOUT_AT(512, 55, tl_k); IVL_TOUT_AT(512, 56, tl_kw); IVL_TOUT_AT(512, 59, tl_v); IVL_TOUT_AT(512, 60, tl_vw);
+    IVL_TOUT_AT(640, 57, tl_k); IVL_TOUT_AT(640, 58, tl_kw); IVL_TOUT_AT(640, 62, tl_v); IVL_TOUT_AT(640, 63, tl_vw);
+   };
+   if (wave < 10) loader_body(std::true_type{});
+   else loader_body(std::false_type{});
+  } else {
+    // ---- compute wavefronts ------------------------------------------------------------------------------------------
+    const int row = tile_row0 + 32 * rg + l31;
+    const bool row_ok = row < p.T;
+    const int band_hi = n_prev + row;
+    const int band_lo = p.W > 0 ? max(0, n_prev + row - p.W + 1) : 0;
+    // band extremes of this wave's 32 rows (lo / hi are monotone in the row)
+    const int wr0 = tile_row0 + 32 * rg, wr1 = max(min(wr0 + 31, p.T - 1), wr0);
+    const int w_hi_min = n_prev + wr0, w_hi_max = n_prev + wr1;
+    const int w_lo_min = p.W > 0 ? max(0, n_prev + wr0 - p.W + 1) : 0;
+    const int w_lo_max = p.W > 0 ? max(0, n_prev + wr1 - p.W + 1) : 0;
+
+    // Q^T fragments (B operand): lane = query row, d = 16 kd + 8 hi .. +7
+    u32x4 qf[8];
+    {
+      const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(row, p.T - 1) * p.q_st + (long long)hq * p.q_sh;
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qp + 16 * kd + 8 * hi5);
+    }
+    if (p.rcos != nullptr) {
+      const long long row_off = ((long long)b * p.T + min(row, p.T - 1)) * SWA_D;
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd)
+        rope_pair(qf[kd], qf[kd + 4], p.rcos, p.rsin, (long long)p.B * p.T * SWA_D, row_off, 16 * kd + 8 * hi5, p.rs0, p.rs1);
+    }
+    if (!row_ok) {
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) qf[kd] = u32x4{0u, 0u, 0u, 0u};
+    }
+    float m_run = -INFINITY, l_run = 0.f;     // l_run: this LANE's part of the row sum (its 16 keys of every tile)
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+
+    const float sc = p.scaling * LOG2E;
+    // per-lane LDS offsets: K fragment row (32 kh + l31), V^T fragment block rows / columns
+    const int k_row_off = (32 * kh + l31) * PF_KSTRIDE + 16 * hi5;
+    const int v_off = PF_V_OFF + (32 * kh + 4 * hi5 + (l15 >> 2)) * PF_VSTRIDE + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
+    auto is_dead = [&](int kt) {                // no row of the wave sees any of its 32 keys of tile kt
+      const int kbeg = kt * SWA_KT + 32 * kh;
+      return kbeg > w_hi_max || kbeg + 31 < w_lo_min;
+    };
+    u32x4 fr[8], pf[2];       // K fragments and V^T fragments time-share one register block
+    float m_use = 0.f, alpha = 1.f;
+    bool need = false;
+    f32x16 sacc;
+    auto row_max = [&](int kt) {      // band mask, running max, rescale factor
+      const int kbeg = kt * SWA_KT + 32 * kh;
+      const bool interior = kbeg >= w_lo_max && kbeg + 31 <= w_hi_min;
+      if (!interior) {
+        const int jb = kbeg + 4 * hi5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jb + (r & 3) + 8 * (r >> 2);
+          const bool vis = row_ok && j >= band_lo && j <= band_hi;
+          sacc[r] = vis ? sacc[r] : -INFINITY;
+        }
+      }
+      // first reader of the MFMA results = an instruction the compiler sees (see swa_fwd_kernel): hazard wait states
+      float rmax = vmax2(__builtin_fmaxf(sacc[0], sacc[1]), sacc[2]);
+      rmax = vmax3(rmax, sacc[3], sacc[4]);
+      rmax = vmax3(rmax, sacc[5], sacc[6]);
+      rmax = vmax3(rmax, sacc[7], sacc[8]);
+      rmax = vmax3(rmax, sacc[9], sacc[10]);
+      rmax = vmax3(rmax, sacc[11], sacc[12]);
+      rmax = vmax3(rmax, sacc[13], sacc[14]);
+      rmax = vmax2(rmax, sacc[15]);
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+      rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+      const float m_new = vmax2(m_run, rmax);
+      m_use = m_new == -INFINITY ? 0.f : m_new;
+      need = __any(m_new > m_run);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_use);     // 1 for a row whose maximum did not move, 0 for a first tile
+      m_run = m_new;
+    };
+    auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
+      // rescale by the factor of the running maximum (1 for a row whose maximum did not move): unconditional - a branch
+      // around it makes the compiler keep two copies of the accumulators and move 64 registers per tile
 #pragma unroll
       for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
       l_run *= alpha;
-    }
-    float rsum = 0.f;
+      float rsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m_use));
-      sacc[r] = pv;
-      rsum += pv;
-    }
-    l_run += rsum;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      pf[ks].x = pack2bf(sacc[8 * ks + 0], sacc[8 * ks + 1]);
-      pf[ks].y = pack2bf(sacc[8 * ks + 2], sacc[8 * ks + 3]);
-      pf[ks].z = pack2bf(sacc[8 * ks + 4], sacc[8 * ks + 5]);
-      pf[ks].w = pack2bf(sacc[8 * ks + 6], sacc[8 * ks + 7]);
-    }
-  };
-  auto qk = [&](int kbuf) {
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd)
-      fr[kd] = *(const u32x4*)(smem + kbuf * PF_K_BYTES + k_row_off + (((2 * kd + hi5) ^ (l31 & 15)) << 4));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[kd]), as_mfma(qf[kd]), sacc, 0, 0, 0);
-  };
-  auto read_v = [&](int vbuf) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const unsigned char* vp = smem + vbuf * PF_V_BYTES + v_off + 16 * ks * PF_VSTRIDE + 64 * mt;
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * PF_VSTRIDE));
-        u32x2 w0, w1;
-        __builtin_memcpy(&w0, &a0, 8);
-        __builtin_memcpy(&w1, &a1, 8);
-        fr[4 * ks + mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m_use));
+        sacc[r] = pv;
+        rsum += pv;
       }
-    asm volatile("" ::: "memory");       // the reads stay ahead of the softmax: their latency hides under it
-  };
-  auto pv = [&]() {
+      l_run += rsum;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks) {
+        pf[ks].x = pack2bf(sacc[8 * ks + 0], sacc[8 * ks + 1]);
+        pf[ks].y = pack2bf(sacc[8 * ks + 2], sacc[8 * ks + 3]);
+        pf[ks].z = pack2bf(sacc[8 * ks + 4], sacc[8 * ks + 5]);
+        pf[ks].w = pack2bf(sacc[8 * ks + 6], sacc[8 * ks + 7]);
+      }
+    };
+    auto qk = [&](int kbuf) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)       // consecutive MFMAs on different accumulators
-        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[4 * ks + mt]), as_mfma(pf[ks]), oacc[mt], 0, 0, 0);
-  };
+      for (int kd = 0; kd < 8; ++kd)
+        fr[kd] = *(const u32x4*)(smem + kbuf * PF_K_BYTES + k_row_off + 32 * kd);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[kd]), as_mfma(qf[kd]), sacc, 0, 0, 0);
+    };
+    auto read_v = [&](int vbuf) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const unsigned char* vp = smem + vbuf * PF_V_BYTES + v_off + 16 * ks * PF_VSTRIDE + 64 * mt;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * PF_VSTRIDE));
+          u32x2 w0, w1;
+          __builtin_memcpy(&w0, &a0, 8);
+          __builtin_memcpy(&w1, &a1, 8);
+          fr[4 * ks + mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+        }
+    };
+    auto pv = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)       // consecutive MFMAs on different accumulators
+          oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[4 * ks + mt]), as_mfma(pf[ks]), oacc[mt], 0, 0, 0);
+    };
 
-  // Two segments per tile, each closed by a barrier:  A(t) = stage tile t+1, S(t) = K Q^T      B(t) = softmax(t), O^T += V^T P^T.
-  // The key-half-1 waves run ONE SEGMENT BEHIND their SIMD partners of key half 0 (one extra barrier before their loop,
-  // one after the others'): the MFMA chain + staging of one wave faces the VALU-bound softmax + PV of the other, from the
-  // same code.  Stage reuse: A(t) overwrites K(t-1) (last read one barrier earlier by the late half) and V(t-2) - V is
-  // triple-buffered because the late half still reads V(t-1) while the early half runs A(t).
-  IVL_T(tr_loop);
-  IVL_TVAR(tr_a); IVL_TVAR(tr_b); IVL_TVAR(tr_wa); IVL_TVAR(tr_wb); IVL_TVAR(tr_st); IVL_TVAR(tr_ld);
-  if (n > 0) {
-    load_tile(kt_begin);
-    store_tile(0, 0);
-    if (n > 1) load_tile(kt_begin + 1);
-  }
-  tile_barrier();
-  if (n > 0) {
-    if (kh == 1) tile_barrier();
-    int vb_cur = 0, vb_next = 1, vb_free = 2;       // V stage of tile t, t+1 and the one tile t+2 will take
-    for (int t = 0; t < n; ++t) {
-      const int kt = kt_begin + t;
-      const bool dead = is_dead(kt);
-      IVL_T(tr0);
-      if (t + 1 < n) {
-        store_tile((t + 1) & 1, vb_next);
-        IVL_T(tr0a);
-        if (t + 2 < n) load_tile(kt + 2);
-        IVL_T(tr0b);
-        IVL_TACC(tr_st, tr0a, tr0); IVL_TACC(tr_ld, tr0b, tr0a);
+    IVL_T(tr_loop);
+    IVL_TVAR(tr_a); IVL_TVAR(tr_b); IVL_TVAR(tr_wa); IVL_TVAR(tr_wb);
+    seg_barrier();                              // tiles 0 and 1 are in LDS
+    {
+      // the second-dispatched half loses every VALU arbitration against its older SIMD partner: static priority evens it
+      if (kh == 1) __builtin_amdgcn_s_setprio(1);
+      if (kh == 1) seg_barrier();
+      int st = 0;
+      for (int t = 0; t < n; ++t) {
+        const int kt = kt_begin + t;
+        const bool dead = is_dead(kt);
+        IVL_T(tr0);
+        if (!dead) {
+          qk(st);
+          row_max(kt);
+        }
+        IVL_T(tr1);
+        seg_barrier();
+        IVL_T(tr2);
+        if (!dead) {
+          read_v(st);
+          exps();
+          pv();
+        }
+        IVL_T(tr3);
+        seg_barrier();
+        IVL_T(tr4);
+        IVL_TACC(tr_a, tr1, tr0); IVL_TACC(tr_wa, tr2, tr1); IVL_TACC(tr_b, tr3, tr2); IVL_TACC(tr_wb, tr4, tr3);
+        st = st == PF_STAGES - 1 ? 0 : st + 1;
       }
-      if (!dead) qk(t & 1);
-      IVL_T(tr1);
-      tile_barrier();
-      IVL_T(tr2);
-      if (!dead) {
-        read_v(vb_cur);
-        row_max(kt);
-        exps();
-        pv();
-      }
-      IVL_T(tr3);
-      tile_barrier();
-      IVL_T(tr4);
-      IVL_TACC(tr_a, tr1, tr0); IVL_TACC(tr_wa, tr2, tr1); IVL_TACC(tr_b, tr3, tr2); IVL_TACC(tr_wb, tr4, tr3);
-      const int tmp = vb_cur;
-      vb_cur = vb_next;
-      vb_next = vb_free;
-      vb_free = tmp;
+      if (kh == 0) seg_barrier();
     }
-    if (kh == 0) tile_barrier();
-  }
-  __syncthreads();
-  IVL_T(tr_end);
+    IVL_T(tr_end);
 
-  // ---- merge the two key halves of every row group through LDS (the K/V stages are free now) ------------------------
-  {
-    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-  }
-  unsigned char* oimg = smem + rg * 32 * PF_OSTRIDE + l31 * PF_OSTRIDE + 16 * hi5;      // + 128 mt + 32 q : d = 32 mt + 8 q + 4 hi
-  float* ml = (float*)(smem + PF_ML_OFF) + (rg * 32 + l31) * 2;
-  if (kh == 1) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4*)(oimg + 128 * mt + 32 * q) = f32x4{oacc[mt][4 * q], oacc[mt][4 * q + 1], oacc[mt][4 * q + 2], oacc[mt][4 * q + 3]};
-    if (hi5 == 0) {
-      ml[0] = m_run;
-      ml[1] = l_run;
+    // ---- merge the two key halves of every row group through LDS (the K/V stages are free behind the next barrier) --
+    {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+      l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+    __syncthreads();
+    unsigned char* oimg = smem + rg * 32 * PF_OSTRIDE + l31 * PF_OSTRIDE + 16 * hi5;      // + 128 mt + 32 q : d = 32 mt + 8 q + 4 hi
+    float* ml = (float*)(smem + PF_ML_OFF) + (rg * 32 + l31) * 2;
+    if (kh == 1) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(oimg + 128 * mt + 32 * q) = f32x4{oacc[mt][4 * q], oacc[mt][4 * q + 1], oacc[mt][4 * q + 2], oacc[mt][4 * q + 3]};
+      if (hi5 == 0) {
+        ml[0] = m_run;
+        ml[1] = l_run;
+      }
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const float m1 = ml[0], l1 = ml[1];
+      const float m = vmax2(m_run, m1);
+      const float mu = m == -INFINITY ? 0.f : m;
+      const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
+      const float l = l_run * a0 + l1 * a1;
+      const float inv = p.nsplit == 1 ? (l > 0.f ? 1.0f / l : 0.f) : 1.0f;
+      const float w0 = a0 * inv, w1 = a1 * inv;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o1 = *(const f32x4*)(oimg + 128 * mt + 32 * q);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = oacc[mt][4 * q + e] * w0 + o1[e] * w1;
+          *(f32x4*)(oimg + 128 * mt + 32 * q) = o;
+        }
+      if (hi5 == 0) {
+        ml[0] = m;
+        ml[1] = l;
+      }
+    }
+    __syncthreads();
+    // ---- whole-row stores by the 512 compute threads ----------------------------------------------------------------
+    if (p.nsplit == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;       // row, 8-channel piece
+        const int t = tile_row0 + r;
+        if (t < p.T) {
+          const unsigned char* src = smem + r * PF_OSTRIDE + c * 32;
+          const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
+          *(u32x4*)(p.o + (((long long)b * p.T + t) * p.Hq + hq) * SWA_D + 8 * c) =
+              u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 5, c = idx & 31;       // row, 4-channel piece
+        const int t = tile_row0 + r;
+        if (t < p.T) {
+          const long long prow = (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
+          *(f32x4*)(p.part_o + prow * SWA_D + 4 * c) = *(const f32x4*)(smem + r * PF_OSTRIDE + c * 16);
+        }
+      }
+      if (tid < PF_QT && tile_row0 + tid < p.T) {
+        const long long prow = (((long long)b * p.nsplit + split) * p.T + tile_row0 + tid) * p.Hq + hq;
+        *(float2*)(p.part_ml + prow * 2) = *(const float2*)(smem + PF_ML_OFF + tid * 8);
+      }
+    }
+    IVL_T(tr_fin);
+    IVL_TOUT(32, tr_loop - tr_start); IVL_TOUT(38, tr_fin - tr_end); IVL_TOUT(39, tr_fin - tr_start); IVL_TOUT(40, kt_end - kt_begin);
+    IVL_TOUT(42, 1); IVL_TOUT(47, tr_end - tr_loop);
+    IVL_TOUT(33, tr_a); IVL_TOUT(34, tr_wa); IVL_TOUT(35, tr_b); IVL_TOUT(36, tr_wb);
+    IVL_TOUT_AT(256, 50, tr_a); IVL_TOUT_AT(256, 51, tr_wa); IVL_TOUT_AT(256, 52, tr_b); IVL_TOUT_AT(256, 53, tr_wb);
+    return;
   }
+  // loader wavefronts: the three barriers of the merge epilogue
   __syncthreads();
-  if (kh == 0) {
-    const float m1 = ml[0], l1 = ml[1];
-    const float m = vmax2(m_run, m1);
-    const float m_use = m == -INFINITY ? 0.f : m;
-    const float a0 = __builtin_amdgcn_exp2f(m_run - m_use), a1 = __builtin_amdgcn_exp2f(m1 - m_use);
-    const float l = l_run * a0 + l1 * a1;
-    const float inv = p.nsplit == 1 ? (l > 0.f ? 1.0f / l : 0.f) : 1.0f;
-    const float w0 = a0 * inv, w1 = a1 * inv;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 o1 = *(const f32x4*)(oimg + 128 * mt + 32 * q);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = oacc[mt][4 * q + e] * w0 + o1[e] * w1;
-        *(f32x4*)(oimg + 128 * mt + 32 * q) = o;
-      }
-    if (hi5 == 0) {
-      ml[0] = m;
-      ml[1] = l;
-    }
-  }
   __syncthreads();
-  // ---- whole-row stores by all 512 threads --------------------------------------------------------------------------
-  if (p.nsplit == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;       // row, 8-channel piece
-      const int t = tile_row0 + r;
-      if (t < p.T) {
-        const unsigned char* src = smem + r * PF_OSTRIDE + c * 32;
-        const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
-        *(u32x4*)(p.o + (((long long)b * p.T + t) * p.Hq + hq) * SWA_D + 8 * c) =
-            u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 512 * i, r = idx >> 5, c = idx & 31;       // row, 4-channel piece
-      const int t = tile_row0 + r;
-      if (t < p.T) {
-        const long long prow = (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
-        *(f32x4*)(p.part_o + prow * SWA_D + 4 * c) = *(const f32x4*)(smem + r * PF_OSTRIDE + c * 16);
-      }
-    }
-    if (tid < PF_QT && tile_row0 + tid < p.T) {
-      const long long prow = (((long long)b * p.nsplit + split) * p.T + tile_row0 + tid) * p.Hq + hq;
-      *(float2*)(p.part_ml + prow * 2) = *(const float2*)(smem + PF_ML_OFF + tid * 8);
-    }
-  }
-  IVL_T(tr_fin);
-  IVL_TOUT(32, tr_loop - tr_start); IVL_TOUT(38, tr_fin - tr_end); IVL_TOUT(39, tr_fin - tr_start); IVL_TOUT(40, kt_end - kt_begin);
-  IVL_TOUT(42, 1); IVL_TOUT(47, tr_end - tr_loop);
-  IVL_TOUT(33, tr_a); IVL_TOUT(34, tr_wa); IVL_TOUT(35, tr_b); IVL_TOUT(36, tr_wb); IVL_TOUT(48, tr_st); IVL_TOUT(49, tr_ld);
-  IVL_TOUT_AT(256, 50, tr_a); IVL_TOUT_AT(256, 51, tr_wa); IVL_TOUT_AT(256, 52, tr_b); IVL_TOUT_AT(256, 53, tr_wb);
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1248,7 +1337,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.n_qtiles = prefill ? (rows + PF_QT - 1) / PF_QT : (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(512), 0, st, p);
+  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(PF_THREADS), 0, st, p);
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
     hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
   else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);

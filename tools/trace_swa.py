@@ -42,8 +42,10 @@ for it in range(3):
     n = max(t[40], 1)
     if t[42]:      # the 128-row prefill kernel (wave 0 = key half 0, wave 4 = key half 1)
         print(f"--- iter {it} (prefill kernel): tiles {t[40]} | prologue {t[32]} | tile loop {t[47]} = {t[47]//n} per tile | epilogue {t[38]} | total {t[39]}")
-        print(f"      key half 0 per tile: A (store {t[48]//n} + loads {t[49]//n} + QK = {t[33]//n}) + wait {t[34]//n} | B (softmax + PV) {t[35]//n} + wait {t[36]//n}")
-        print(f"      key half 1 per tile: A (stage + QK) {t[50]//n} + wait {t[51]//n} | B (softmax + PV) {t[52]//n} + wait {t[53]//n}")
+        print(f"      key half 0 per tile: A (QK + row max) {t[33]//n} + wait {t[34]//n} | B (exps + PV) {t[35]//n} + wait {t[36]//n}")
+        print(f"      key half 1 per tile: A (QK + row max) {t[50]//n} + wait {t[51]//n} | B (exps + PV) {t[52]//n} + wait {t[53]//n}")
+        print(f"      loader wave 8 (K) per tile: issue DMA {t[55]//n} + wait {t[56]//n} | vmcnt {t[59]//n} + wait {t[60]//n}")
+        print(f"      loader wave 10 (V) per tile: vmcnt {t[57]//n} + wait {t[58]//n} | issue DMA {t[62]//n} + wait {t[63]//n}")
         continue
     print(f"--- iter {it}: tiles {t[40]} | prologue {t[32]} | per tile: barrier1 {t[33]//n} store+barrier2 {t[34]//n} "
           f"QK issue+next loads {t[35]//n} softmax {t[36]//n} PV {t[37]//n} (sum {sum(t[33:38])//n}) | epilogue {t[38]} | total {t[39]} "
