@@ -138,7 +138,7 @@ def kernel_timings(device, chunk, window, only=None):
     q, k, v, g, beta = gdn_inputs(T)
     add("gdn_chunk(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
         q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        20, 27, "hbm", 24672.0 * T + sbytes)
+        20, 0, "hbm", 24672.0 * T + sbytes)
     add("gdn_chunk_fp8(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
         q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
         20, 0, "hbm", 24672.0 * T + sbytes)
@@ -158,8 +158,14 @@ def kernel_timings(device, chunk, window, only=None):
     cw = [rn(D_, 1, 4) for D_ in (Dq, Dk, Dv)]
     cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
     A32, dt32 = torch.randn(H, device=device, generator=g_), torch.randn(H, device=device, generator=g_)
+    # the step's GDN layers run the chunk kernel WITH its front end (3 convs + SiLU + gate math inside the pre-pass): the
+    # projection is read once (16,416 B/token incl. the a / b gate inputs) and q / k / v / g / beta never reach HBM;
+    # algorithmic bytes per token: 16,416 (projection slice) + 8,192 (o) = 24,608 B + the state
+    add("gdn_chunk_fused(convs+gates+prepare+scan)", lambda: ops.gdn_chunk_fused(
+        proj, cols, cw, cs, cs, A32, dt32, H, K, V, initial_state=state, final_state_out=state), 20, 27, "hbm",
+        24608.0 * T + sbytes)
     add("gdn_prologue(3 convs + gates)", lambda: ops.gdn_prologue(proj, cols, cw, cs, cs, A32, dt32, H, Dq, Dk, Dv),
-        50, 27, "hbm", 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2))
+        50, 0, "hbm", 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2))
     xo, wn = rn(B, T, H, V), rn(V)
     add("rmsnorm_swish_gate", lambda: ops.rmsnorm_swish_gate_strided(xo, proj[..., Dq + Dk + Dv:], ld, wn, 1e-5),
         50, 27, "hbm", 3.0 * T * H * V * 2)
@@ -235,8 +241,10 @@ def pmc_traffic(kernel_name, chunk, window):
         return None
     k = json.load(open(files[-1]))["kernels"]
     want = {
-        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
-        "swa_prefill": [("ivl::swa_fwd_kernel<false,", 131072), ("ivl::swa_combine_kernel<8>", 262144)],
+        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
+        "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, true>", 32768),
+                                                      ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
+        "swa_prefill": [("ivl::swa_prefill_kernel", 196608), ("ivl::swa_combine_kernel<8>", 262144)],
         "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
         "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 2
+#define IVL_ABI_VERSION 3
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -82,6 +82,25 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
                       void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
                       int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, int mma_dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chunked gated delta rule WITH its front end, from the mixer's single projection buffer: the three causal short
+ * convolutions (+SiLU, carry-in from / carry-out to the conv states) and the gate math run inside the chunk-parallel
+ * pre-pass, so q / k / v / g / beta never reach HBM and ivl_gdn_prologue_fwd's launch disappears.
+ * Replaces std:1253-1283 (q/k/v_conv1d), std:1293-1294 (beta, g) and std:1299-1323 (chunk_gated_delta_rule with
+ *   use_qk_l2norm_in_kernel=True) of Qwen3NextGatedDeltaNet.forward in one call; bit-identical to ivl_gdn_prologue_fwd
+ *   followed by ivl_gdn_chunk_fwd (same arithmetic, same bf16 rounding points).
+ * proj bf16 [B*T, ld]; col_q / col_k / col_v = first column of head 0 of the q / k / v blocks ([H*K], [H*K], [H*V]),
+ * col_a / col_b = first column of the a / b gate inputs ([H]); conv taps wq / wk / wv bf16 [D, 1, 4]; conv states
+ * [B, D, 4] bf16 (in: NULL = zero history; out: NULL = not wanted; out may alias in).  The rest as ivl_gdn_chunk_fwd
+ * (q/k l2norm always on, as the reference calls it).
+ * ------------------------------------------------------------------------------------------- */
+IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
+                            const void* wq, const void* wk, const void* wv, const void* sq_in, const void* sk_in,
+                            const void* sv_in, void* sq_out, void* sk_out, void* sv_out, const float* A_log,
+                            const float* dt_bias, void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype, int B,
+                            int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gate math: beta = sigmoid(b) (bf16), g = -exp(A_log) * softplus(a + dt_bias) (fp32).
@@ -162,6 +181,9 @@ typedef struct ivl_swa_args {
   int mma_dtype;            /* IVL_BF16 (the reference's precision) or IVL_FP8_E4M3: the single-token decode step
                                (T * Hq/Hkv <= 64 packed rows) rounds q, K, V and the probabilities to e4m3 for the two
                                products (BASELINE.json configs[4]); longer calls always run in bf16                  */
+  int append_new;           /* != 0: after the attention, also append the call's T tokens to the ring (what ivl_swa_cache_append
+                               does, same rope arguments) - inside the split-KV combine launch when there is one, so that a
+                               layer costs one launch less.  Needs a ring cache and T_new == T.                      */
 } ivl_swa_args;
 
 IVL_API size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);

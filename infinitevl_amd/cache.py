@@ -114,11 +114,10 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
             raise ValueError(f"SWA pre-allocated batch_size={self.batch_size}, but got B={B}")
         if Hkv != self.num_kv_heads or D != self.head_dim:
             raise ValueError(f"SWA head dim mismatch: got H={Hkv},D={D}, expect H={self.num_kv_heads},D={self.head_dim}")
+        # attention over (ring ++ new), then the append: one call (the append rides in the split-KV combine launch)
         o = ops.swa_forward(q, k_new, v_new, window=window, scaling=scaling,
                             k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev, mma_dtype=mma_dtype,
-                            rope=rope)
-        if self.capacity > 0:
-            ops.swa_cache_append(k_new, v_new, self._buf_keys, self._buf_values, pos_dev=self._pos_dev, rope=rope)
+                            rope=rope, append=self.capacity > 0)
         if self._advances_counter:
             ops.counter_add(self._pos_dev, T)
         self.advance(T)

@@ -34,6 +34,7 @@
 #include <mutex>
 
 #include "ivl_common.h"
+#include <type_traits>
 
 namespace ivl {
 IVL_TRACE_DECL(gdn)
@@ -141,10 +142,62 @@ __device__ __forceinline__ u32x4 frag_tr32(const bf16_t* X, int ld, int k0, int 
   return u32x4{w0.x, w0.y, w1.x, w1.y};
 }
 
-template <bool F8>
+// Fused front end (FUSED = true): the pre-pass reads the mixer's ONE projection buffer itself and applies the three causal
+// short convolutions (kernel 4, + SiLU, carry-in from / carry-out to the conv states, fla:modules/convolution.py via
+// std:1253-1283) and the gate math (std:1293-1294) on the way in - the q / k / v / g / beta tensors of the unfused path never
+// exist in HBM and the separate prologue launch disappears.  Same arithmetic, same bf16 rounding points as
+// ivl_gdn_prologue_fwd followed by the plain pre-pass: the two paths agree bit for bit.
+struct PrepFused {
+  const bf16_t* proj; long long ld;                 // [B*T, ld] bf16
+  int col_q, col_k, col_v, col_a, col_b;            // first column of q / k / v (head 0) and of the a / b gate inputs
+  const bf16_t* w[3];                               // conv taps [D, 1, 4] bf16 of q, k, v
+  const bf16_t* st_in[3];                           // conv states [B, D, 4] bf16 (NULL: zero history)
+  bf16_t* st_out[3];                                // new conv states (may alias st_in; NULL: not wanted)
+  const float* A_log; const float* dt_bias;         // [H] fp32
+};
+
+// causal 4-tap conv + SiLU of NR consecutive tokens x 8 channels: xr[0..2] = the three tokens before the run, xr[3..] the
+// run; taps of channel c = (w[c / 2] .x/.y | .z/.w).  fp32 accumulation in tap order, output rounded to bf16 (the unfused
+// path's tensors are bf16).
+template <int NR>
+__device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x4* out) {
+  const unsigned int ww[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
+                               w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
+  float wf[8][4];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    wf[c][0] = bflo(ww[2 * c]); wf[c][1] = bfhi(ww[2 * c]); wf[c][2] = bflo(ww[2 * c + 1]); wf[c][3] = bfhi(ww[2 * c + 1]);
+  }
+  float win[3][8];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const u32x4 x = xr[k];
+    win[k][0] = bflo(x.x); win[k][1] = bfhi(x.x); win[k][2] = bflo(x.y); win[k][3] = bfhi(x.y);
+    win[k][4] = bflo(x.z); win[k][5] = bfhi(x.z); win[k][6] = bflo(x.w); win[k][7] = bfhi(x.w);
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const u32x4 x = xr[k + 3];
+    const float cur[8] = {bflo(x.x), bfhi(x.x), bflo(x.y), bfhi(x.y), bflo(x.z), bfhi(x.z), bflo(x.w), bfhi(x.w)};
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = wf[c][0] * win[0][c];
+      a = fmaf(wf[c][1], win[1][c], a);
+      a = fmaf(wf[c][2], win[2][c], a);
+      a = fmaf(wf[c][3], cur[c], a);
+      a = a * sigmoidf_(a);
+      o[c] = a;
+      win[0][c] = win[1][c]; win[1][c] = win[2][c]; win[2][c] = cur[c];
+    }
+    out[k] = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+  }
+}
+
+template <bool F8, bool FUSED>
 __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ g,
-    const bf16_t* __restrict__ beta, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
+    const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using R = Rec<F8>;
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
@@ -171,31 +224,150 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * R::STRIDE;
 
   // ---- P0: every global load of the chunk is issued up front (clamped rows, zeroed later) ------------------
-  const int oct = tid & 15, r0 = tid >> 4;         // thread -> rows r0, r0 + 32; 16-byte column octet
-  u32x4 kraw[2], qraw[2];
-  bf16_t braw[2];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = min(r0 + 32 * rr, nvalid - 1);
-    const size_t tok = ((size_t)b * T + t0 + row) * H + h;
-    kraw[rr] = *(const u32x4*)(k + tok * GK + 8 * oct);
-    qraw[rr] = *(const u32x4*)(q + tok * GK + 8 * oct);
-    braw[rr] = beta[tok];
-  }
-  u32x4 vraw[8];                                     // waves 4-7: the chunk's v tile, 8 x 16 bytes per thread (rows vr + 8 i)
+  // plain : thread -> rows r0, r0 + 32 of q and k, 16-byte column octet; waves 4-7 also rows vr + 8 i of v
+  // fused : waves 0-3 -> rows 4 r0 .. 4 r0 + 3 of q and k (r0 < 16), waves 4-7 -> rows 8 vr .. 8 vr + 7 of v: runs of
+  //         consecutive tokens, so that the three tokens in front of a run are loaded once
+  const int oct = tid & 15, r0 = FUSED ? (tid >> 4) & 15 : tid >> 4;
+  constexpr int NQK = FUSED ? 4 : 2;                 // q / k rows per thread
+  u32x4 kraw[NQK], qraw[NQK];
+  bf16_t braw[NQK];
+  u32x4 vraw[8];                                     // waves 4-7: the chunk's v tile, 8 x 16 bytes per thread
   const int t2v = tid - 256, voct = t2v & 31, vr = t2v >> 5;
-  if (wave_u >= 4) {
+  auto qk_row = [&](int rr) { return FUSED ? 4 * r0 + rr : r0 + 32 * rr; };
+  auto v_row = [&](int i) { return FUSED ? 8 * vr + i : vr + 8 * i; };
+  if constexpr (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = min(vr + 8 * i, nvalid - 1);
-      vraw[i] = *(const u32x4*)(v + (((size_t)b * T + t0 + row) * H + h) * GV + 8 * voct);
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = min(r0 + 32 * rr, nvalid - 1);
+      const size_t tok = ((size_t)b * T + t0 + row) * H + h;
+      kraw[rr] = *(const u32x4*)(k + tok * GK + 8 * oct);
+      qraw[rr] = *(const u32x4*)(q + tok * GK + 8 * oct);
+      braw[rr] = beta[tok];
+    }
+    if (wave_u >= 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = min(vr + 8 * i, nvalid - 1);
+        vraw[i] = *(const u32x4*)(v + (((size_t)b * T + t0 + row) * H + h) * GV + 8 * voct);
+      }
+    }
+  } else {
+    const bf16_t* xb = pf.proj + (size_t)b * T * pf.ld;              // row t at xb + t * ld
+    // rows of a run of NR tokens starting at chunk row `first`: global times t0 + first - 3 .. t0 + first + NR - 1,
+    // clamped into the sequence (times < 0 come from the conv state, rows past the end are zeroed downstream)
+    auto load_run = [&](u32x4* xr, int first, auto nr_tag, int col) {
+      constexpr int NR = decltype(nr_tag)::value;
+#pragma unroll
+      for (int kk = 0; kk < NR + 3; ++kk) {
+        int tg = t0 + first - 3 + kk;
+        tg = tg < 0 ? 0 : (tg > T - 1 ? T - 1 : tg);
+        xr[kk] = *(const u32x4*)(xb + (size_t)tg * pf.ld + col);
+      }
+    };
+    // the history of a run that starts at time 0 is the conv state: state[c][1..3] = times -3, -2, -1
+    auto history = [&](u32x4* xr, const bf16_t* st_in, int dch) {
+      u32x4 s4[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+      if (st_in != nullptr) {
+        const u32x4* sp = (const u32x4*)(st_in + ((size_t)b * H * (dch == 2 ? GV : GK) + (size_t)h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct)) * 4);
+        s4[0] = sp[0]; s4[1] = sp[1]; s4[2] = sp[2]; s4[3] = sp[3];
+      }
+      const unsigned int ss[16] = {s4[0].x, s4[0].y, s4[0].z, s4[0].w, s4[1].x, s4[1].y, s4[1].z, s4[1].w,
+                                   s4[2].x, s4[2].y, s4[2].z, s4[2].w, s4[3].x, s4[3].y, s4[3].z, s4[3].w};
+      // channel c: ss[2c] = (state[c][0], state[c][1]), ss[2c + 1] = (state[c][2], state[c][3])
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        unsigned int hw[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const unsigned int word = ss[2 * c + ((kk + 1) >> 1)];
+          hw[c] = ((kk + 1) & 1) ? word >> 16 : word & 0xffffu;
+        }
+        xr[kk] = u32x4{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16)};
+      }
+    };
+    // new conv state = the last four inputs of the sequence ([old state, x] when T < 4): written by the thread that read
+    // the old one (chunk 0, run 0), so that st_out may alias st_in
+    auto put_state = [&](const u32x4* hist3, bf16_t* st_out, const bf16_t* st_in, int col, int dch) {
+      if (st_out == nullptr) return;
+      const int D = H * (dch == 2 ? GV : GK), d0 = h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct);
+      unsigned int ns[8][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = T + j;                                           // index into ext = [state(4), x(T)]
+        u32x4 xv = u32x4{0u, 0u, 0u, 0u};
+        if (e >= 4) xv = *(const u32x4*)(xb + (size_t)(e - 4) * pf.ld + col);
+        const unsigned int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          unsigned int val = (c & 1) ? xs[c >> 1] >> 16 : xs[c >> 1] & 0xffffu;
+          if (e < 4) {                                                 // e in 1..3 (T = 1..3... never 0: T >= 1): old state[c][e]
+            const u32x4 hx = e == 1 ? hist3[0] : (e == 2 ? hist3[1] : hist3[2]);
+            const unsigned int hs[4] = {hx.x, hx.y, hx.z, hx.w};
+            val = (c & 1) ? hs[c >> 1] >> 16 : hs[c >> 1] & 0xffffu;
+          }
+          ns[c][j] = val;
+        }
+      }
+      (void)st_in;
+      u32x4* op = (u32x4*)(st_out + ((size_t)b * D + d0) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        op[i] = u32x4{ns[2 * i][0] | (ns[2 * i][1] << 16), ns[2 * i][2] | (ns[2 * i][3] << 16),
+                      ns[2 * i + 1][0] | (ns[2 * i + 1][1] << 16), ns[2 * i + 1][2] | (ns[2 * i + 1][3] << 16)};
+    };
+    const bool own_state = t0 == 0;                                    // this workgroup holds time 0
+    if (wave_u < 4) {
+      u32x4 xq[7], xk[7], wq[4], wk[4];
+      const int cq = pf.col_q + h * GK + 8 * oct, ck = pf.col_k + h * GK + 8 * oct;
+      load_run(xq, 4 * r0, std::integral_constant<int, 4>{}, cq);
+      load_run(xk, 4 * r0, std::integral_constant<int, 4>{}, ck);
+      const u32x4* wqp = (const u32x4*)(pf.w[0] + ((size_t)h * GK + 8 * oct) * 4);
+      const u32x4* wkp = (const u32x4*)(pf.w[1] + ((size_t)h * GK + 8 * oct) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { wq[i] = wqp[i]; wk[i] = wkp[i]; }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {                                 // beta = bf16(sigmoid(b)) (std:1293)
+        const int tg = min(t0 + 4 * r0 + rr, T - 1);
+        const float bv = bf2f(xb[(size_t)tg * pf.ld + pf.col_b + h]);
+        braw[rr] = f2bf(1.0f / (1.0f + expf(-bv)));
+      }
+      if (own_state && r0 == 0) {
+        history(xq, pf.st_in[0], 0);
+        history(xk, pf.st_in[1], 1);
+        put_state(xq, pf.st_out[0], pf.st_in[0], cq, 0);
+        put_state(xk, pf.st_out[1], pf.st_in[1], ck, 1);
+      }
+      conv4_silu<4>(xq, wq, qraw);
+      conv4_silu<4>(xk, wk, kraw);
+    } else {
+      u32x4 xv[11], wv[4];
+      const int cv = pf.col_v + h * GV + 8 * voct;
+      load_run(xv, 8 * vr, std::integral_constant<int, 8>{}, cv);
+      const u32x4* wvp = (const u32x4*)(pf.w[2] + ((size_t)h * GV + 8 * voct) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wv[i] = wvp[i];
+      if (own_state && vr == 0) {
+        history(xv, pf.st_in[2], 2);
+        put_state(xv, pf.st_out[2], pf.st_in[2], cv, 2);
+      }
+      conv4_silu<8>(xv, wv, vraw);
     }
   }
   // ---- P1a (wave 0): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta ---------------
   if (wave_u == 0) {
     const size_t tok = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
-    const float g_ld = g[tok];
-    const float b_ld = bf2f(beta[tok]);
+    float g_ld, b_ld;
+    if constexpr (FUSED) {                           // g = -exp(A_log) softplus(a + dt_bias), beta = bf16(sigmoid(b)) (std:1293-1294)
+      const bf16_t* row = pf.proj + ((size_t)b * T + t0 + min(lane, nvalid - 1)) * pf.ld;
+      const float av = bf2f(row[pf.col_a + h]) + pf.dt_bias[h];
+      const float bv = bf2f(row[pf.col_b + h]);
+      const float sp = av > 20.f ? av : log1pf(expf(av));
+      g_ld = -expf(pf.A_log[h]) * sp;
+      b_ld = bf2f(f2bf(1.0f / (1.0f + expf(-bv))));
+    } else {
+      g_ld = g[tok];
+      b_ld = bf2f(beta[tok]);
+    }
     float gv = lane < nvalid ? g_ld : 0.f;
     const float bv = lane < nvalid ? b_ld : 0.f;
 #pragma unroll
@@ -214,8 +386,9 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = r0 + 32 * rr;
+  for (int rr = 0; rr < NQK; ++rr) {
+    if (FUSED && wave_u >= 4) break;                 // fused: waves 4-7 hold v
+    const int row = qk_row(rr);
     const bool ok = row < nvalid;
     const u32x4 kv = kraw[rr], qv = qraw[rr];
     float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
@@ -363,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   auto write_beta_v = [&](int i0) {
 #pragma unroll
     for (int i = i0; i < i0 + 4; ++i) {
-      const int row = vr + 8 * i;
+      const int row = v_row(i);
       const u32x4 vv = vraw[i];
       const float bt = s_beta[row];
       *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
@@ -876,8 +1049,10 @@ static void gdn_chunk_init_device() {
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 63], [] {
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false>, attr, P_BYTES);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false, false>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, false>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false, true>, attr, P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, false>, attr, scan_lds_bytes(4, false));
     (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2, false>, attr, scan_lds_bytes(2, false));
     (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, true>, attr, scan_lds_bytes(4, true));
@@ -894,7 +1069,7 @@ extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int 
 }
 
 template <bool F8>
-static int gdn_chunk_launch(const void* q, const void* k, const void* v, const float* g, const void* beta, void* o,
+static int gdn_chunk_launch(const void* q, const void* k, const void* v, const float* g, const void* beta, const PrepFused* pf, void* o,
                             const void* h0, int h0_dtype, void* ht, int ht_dtype, int B, int T, int H, float scale,
                             int use_qk_l2norm, unsigned char* wsb, hipStream_t st) {
   const int NT = (T + GC - 1) / GC;
@@ -907,9 +1082,14 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
     const bool first = c0 == 0, last = c0 + nseg >= NT;
-    hipLaunchKernelGGL(gdn_chunk_prepare_kernel<F8>, dim3(nseg, B * H), dim3(512), P_BYTES, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, wsb, T, H, c0 * GC, nseg,
-                       use_qk_l2norm);
+    if (pf != nullptr)
+      hipLaunchKernelGGL((gdn_chunk_prepare_kernel<F8, true>), dim3(nseg, B * H), dim3(512), P_BYTES, st, (const bf16_t*)nullptr,
+                         (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const bf16_t*)nullptr, *pf, wsb, T, H,
+                         c0 * GC, nseg, use_qk_l2norm);
+    else
+      hipLaunchKernelGGL((gdn_chunk_prepare_kernel<F8, false>), dim3(nseg, B * H), dim3(512), P_BYTES, st, (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, PrepFused{}, wsb, T, H, c0 * GC, nseg,
+                         use_qk_l2norm);
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
     if (rc != IVL_OK) return rc;
     const void* hin = first ? h0 : (const void*)carry;
@@ -945,8 +1125,45 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
               "ivl_gdn_chunk_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
   gdn_chunk_init_device();
   if (mma_dtype == IVL_FP8_E4M3)
-    return gdn_chunk_launch<true>(q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
+    return gdn_chunk_launch<true>(q, k, v, g, beta, nullptr, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
                                   (unsigned char*)workspace, (hipStream_t)stream);
-  return gdn_chunk_launch<false>(q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
+  return gdn_chunk_launch<false>(q, k, v, g, beta, nullptr, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
+                                 (unsigned char*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
+                                       const void* wq, const void* wk, const void* wv, const void* sq_in, const void* sk_in,
+                                       const void* sv_in, void* sq_out, void* sk_out, void* sv_out, const float* A_log,
+                                       const float* dt_bias, void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype, int B,
+                                       int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  IVL_REQUIRE(proj && wq && wk && wv && A_log && dt_bias && o, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: NULL pointer");
+  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
+  IVL_REQUIRE(K == GK && V == GV && conv_width == 4, IVL_ERR_UNSUPPORTED,
+              "ivl_gdn_chunk_fused_fwd: built for K=128, V=256, conv width 4 (got %d,%d,%d)", K, V, conv_width);
+  IVL_REQUIRE(ld % 8 == 0 && col_q % 8 == 0 && col_k % 8 == 0 && col_v % 8 == 0 && col_q >= 0 && col_k >= 0 && col_v >= 0 &&
+                  col_a >= 0 && col_b >= 0 && col_a + H <= ld && col_b + H <= ld,
+              IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: projection columns must be 16-byte aligned and inside the row (ld=%lld)",
+              (long long)ld);
+  IVL_REQUIRE((h0 == nullptr || h0_dtype == IVL_F32 || h0_dtype == IVL_BF16) &&
+              (ht == nullptr || ht_dtype == IVL_F32 || ht_dtype == IVL_BF16),
+              IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: state dtype must be IVL_F32 or IVL_BF16");
+  IVL_REQUIRE(mma_dtype == IVL_BF16 || mma_dtype == IVL_FP8_E4M3, IVL_ERR_INVALID_ARG,
+              "ivl_gdn_chunk_fused_fwd: mma_dtype must be IVL_BF16 or IVL_FP8_E4M3 (got %d)", mma_dtype);
+  const size_t need = ivl_gdn_chunk_workspace_bytes(B, T, H, K, V);
+  IVL_REQUIRE(workspace != nullptr && workspace_bytes >= need, IVL_ERR_WORKSPACE,
+              "ivl_gdn_chunk_fused_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+  gdn_chunk_init_device();
+  PrepFused pf;
+  pf.proj = (const bf16_t*)proj; pf.ld = ld;
+  pf.col_q = col_q; pf.col_k = col_k; pf.col_v = col_v; pf.col_a = col_a; pf.col_b = col_b;
+  pf.w[0] = (const bf16_t*)wq; pf.w[1] = (const bf16_t*)wk; pf.w[2] = (const bf16_t*)wv;
+  pf.st_in[0] = (const bf16_t*)sq_in; pf.st_in[1] = (const bf16_t*)sk_in; pf.st_in[2] = (const bf16_t*)sv_in;
+  pf.st_out[0] = (bf16_t*)sq_out; pf.st_out[1] = (bf16_t*)sk_out; pf.st_out[2] = (bf16_t*)sv_out;
+  pf.A_log = A_log; pf.dt_bias = dt_bias;
+  if (mma_dtype == IVL_FP8_E4M3)
+    return gdn_chunk_launch<true>(nullptr, nullptr, nullptr, nullptr, nullptr, &pf, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, 1,
+                                  (unsigned char*)workspace, (hipStream_t)stream);
+  return gdn_chunk_launch<false>(nullptr, nullptr, nullptr, nullptr, nullptr, &pf, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, 1,
                                  (unsigned char*)workspace, (hipStream_t)stream);
 }

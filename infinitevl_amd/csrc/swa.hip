@@ -1135,14 +1135,55 @@ __global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
   }
 }
 
+// Ring append folded into the combine launch (ivl_swa_args.append_new): the blocks behind the combine blocks copy the
+// call's tokens into the ring.  The attention kernel has finished by then (stream order), so no reader of the old
+// slots is left; one launch per layer and step instead of two.
+struct AppendArgs {
+  const bf16_t* k_new; const bf16_t* v_new; long long kn_sb, kn_st, kn_sh;
+  bf16_t* k_cache; bf16_t* v_cache;
+  int B, T, Hkv, C; long long pos; const long long* pos_dev;
+  const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
+  int first_block;          // index of the first append block in the grid; < 0: no append
+};
+// token t of the call -> slot (pos + t) % C ; only the last min(T, C) tokens are written
+__device__ __forceinline__ void ring_append(const AppendArgs& a, long long block, long long nblocks) {
+  const long long pos = a.pos_dev ? *a.pos_dev : a.pos;
+  const int t_first = a.T > a.C ? a.T - a.C : 0;
+  const int nt = a.T - t_first;
+  const long long total = (long long)a.B * nt * a.Hkv * (SWA_D / 8);
+  for (long long idx = block * blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
+    const int ch = (int)(idx % (SWA_D / 8));
+    const int hk = (int)((idx / (SWA_D / 8)) % a.Hkv);
+    const int tt = (int)((idx / ((long long)(SWA_D / 8) * a.Hkv)) % nt) + t_first;
+    const int b = (int)(idx / ((long long)(SWA_D / 8) * a.Hkv * nt));
+    const int slot = (int)((pos + tt) % a.C);
+    const long long src = (long long)b * a.kn_sb + (long long)tt * a.kn_st + (long long)hk * a.kn_sh + ch * 8;
+    const long long dst = (((long long)b * a.Hkv + hk) * a.C + slot) * SWA_D + ch * 8;
+    u32x4 kv = *(const u32x4*)(a.k_new + src);
+    if (a.rcos != nullptr) {                     // rotate on the way into the ring (same arithmetic as the attention kernel)
+      const u32x4 part = *(const u32x4*)(a.k_new + src + ((ch ^ 8) - ch) * 8);
+      u32x4 lo = ch < 8 ? kv : part, hi = ch < 8 ? part : kv;
+      rope_pair(lo, hi, a.rcos, a.rsin, (long long)a.B * a.T * SWA_D, ((long long)b * a.T + tt) * SWA_D, (ch & 7) * 8, a.rs0, a.rs1);
+      kv = ch < 8 ? lo : hi;
+    }
+    *(u32x4*)(a.k_cache + dst) = kv;
+    *(u32x4*)(a.v_cache + dst) = *(const u32x4*)(a.v_new + src);
+  }
+}
+
 // merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane; every split's loads are
 // issued before the first use (template on the split count so the loop is fully unrolled)
 template <int NS>
 __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                         bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit) {
+                                                         bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit, AppendArgs ap) {
+  if (ap.first_block >= 0 && (int)blockIdx.x >= ap.first_block) {
+    ring_append(ap, (long long)blockIdx.x - ap.first_block, (long long)gridDim.x - ap.first_block);
+    return;
+  }
+  const int ncb = ap.first_block >= 0 ? ap.first_block : (int)gridDim.x;       // combine blocks
   const int lane = threadIdx.x & 63;
   const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long nw = ((long long)ncb * blockDim.x) >> 6;
   for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
     const long long b = r / rows_per_b, rr = r % rows_per_b;
     float ms[NS], ls[NS];
@@ -1176,10 +1217,15 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
 // (its running max / sum -> weight 2^(m_s - m)), then the wave walks the splits with the weights broadcast by
 // v_readlane while every lane accumulates its 2 d-values; loads are issued 8 splits at a time.
 __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                              bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit) {
+                                                              bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit, AppendArgs ap) {
+  if (ap.first_block >= 0 && (int)blockIdx.x >= ap.first_block) {
+    ring_append(ap, (long long)blockIdx.x - ap.first_block, (long long)gridDim.x - ap.first_block);
+    return;
+  }
+  const int ncb = ap.first_block >= 0 ? ap.first_block : (int)gridDim.x;       // combine blocks
   const int lane = threadIdx.x & 63;
   const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long nw = ((long long)ncb * blockDim.x) >> 6;
   for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
     const long long b = r / rows_per_b, rr = r % rows_per_b;
     const bool on = lane < nsplit;
@@ -1210,35 +1256,8 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
   }
 }
 
-// ring append: token t of the call -> slot (pos + t) % C ; only the last min(T, C) tokens are written
-__global__ __launch_bounds__(256) void swa_cache_append_kernel(
-    const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, long long kn_sb, long long kn_st, long long kn_sh,
-    bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int B, int T, int Hkv, int C,
-    long long pos_host, const long long* pos_dev, const bf16_t* __restrict__ rcos, const bf16_t* __restrict__ rsin, int rs0, int rs1) {
-  const long long pos = pos_dev ? *pos_dev : pos_host;
-  const int t_first = T > C ? T - C : 0;
-  const int nt = T - t_first;
-  const long long total = (long long)B * nt * Hkv * (SWA_D / 8);
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(idx % (SWA_D / 8));
-    const int hk = (int)((idx / (SWA_D / 8)) % Hkv);
-    const int tt = (int)((idx / ((long long)(SWA_D / 8) * Hkv)) % nt) + t_first;
-    const int b = (int)(idx / ((long long)(SWA_D / 8) * Hkv * nt));
-    const int slot = (int)((pos + tt) % C);
-    const long long src = (long long)b * kn_sb + (long long)tt * kn_st + (long long)hk * kn_sh + ch * 8;
-    const long long dst = (((long long)b * Hkv + hk) * C + slot) * SWA_D + ch * 8;
-    u32x4 kv = *(const u32x4*)(k_new + src);
-    if (rcos != nullptr) {                       // rotate on the way into the ring (same arithmetic as the attention kernel)
-      const u32x4 part = *(const u32x4*)(k_new + src + ((ch ^ 8) - ch) * 8);
-      u32x4 lo = ch < 8 ? kv : part, hi = ch < 8 ? part : kv;
-      rope_pair(lo, hi, rcos, rsin, (long long)B * T * SWA_D, ((long long)b * T + tt) * SWA_D, (ch & 7) * 8, rs0, rs1);
-      kv = ch < 8 ? lo : hi;
-    }
-    *(u32x4*)(k_cache + dst) = kv;
-    *(u32x4*)(v_cache + dst) = *(const u32x4*)(v_new + src);
-  }
-}
+// stand-alone ring append (ivl_swa_cache_append, and ivl_swa_fwd with append_new when no combine launch follows)
+__global__ __launch_bounds__(256) void swa_cache_append_kernel(AppendArgs ap) { ring_append(ap, blockIdx.x, gridDim.x); }
 
 // 16-row query groups per wave.  128-row workgroups halve the LDS traffic per MFMA (1.4x per-tile efficiency) but
 // also halve the number of workgroups: they pay once a call still offers >= 4 workgroups per CU (B*T*Hq >= 128K rows);
@@ -1293,6 +1312,9 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
               IVL_ERR_UNSUPPORTED, "ivl_swa_fwd: the fp8 decode step takes rotated q / k (apply ivl_mrope_fwd first)");
   IVL_REQUIRE(a->mma_dtype == IVL_BF16 || a->mma_dtype == IVL_FP8_E4M3, IVL_ERR_INVALID_ARG,
               "ivl_swa_fwd: mma_dtype must be IVL_BF16 or IVL_FP8_E4M3 (got %d)", a->mma_dtype);
+  IVL_REQUIRE(!a->append_new || (a->cache_capacity > 0 && a->T_new == a->T), IVL_ERR_INVALID_ARG,
+              "ivl_swa_fwd: append_new needs a ring cache and T_new == T (got capacity %d, T_new %d, T %d)", a->cache_capacity,
+              a->T_new, a->T);
   // new-key rows are addressed with 32-bit element offsets from the (batch, kv-head) base
   IVL_REQUIRE((long long)a->T_new * a->kn_st < (1LL << 32) && a->kn_st >= 0, IVL_ERR_UNSUPPORTED,
               "ivl_swa_fwd: T_new * kn_st = %lld elements exceeds the 32-bit row addressing of the kernel (split the call)",
@@ -1345,15 +1367,33 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p);
   int rc = check_launch("ivl_swa_fwd");
   if (rc != IVL_OK) return rc;
+  AppendArgs ap;
+  ap.first_block = -1;
+  int append_blocks = 0;
+  if (a->append_new) {
+    ap.k_new = p.k_new; ap.v_new = p.v_new; ap.kn_sb = p.kn_sb; ap.kn_st = p.kn_st; ap.kn_sh = p.kn_sh;
+    ap.k_cache = (bf16_t*)a->k_cache; ap.v_cache = (bf16_t*)a->v_cache;
+    ap.B = a->B; ap.T = a->T; ap.Hkv = a->Hkv; ap.C = a->cache_capacity; ap.pos = a->pos; ap.pos_dev = p.pos_dev;
+    ap.rcos = p.rcos; ap.rsin = p.rsin; ap.rs0 = p.rs0; ap.rs1 = p.rs1;
+    const int nt = a->T > a->cache_capacity ? a->cache_capacity : a->T;
+    long long ab = ((long long)a->B * nt * a->Hkv * (SWA_D / 8) + 255) / 256;
+    append_blocks = (int)(ab > 2048 ? 2048 : ab);
+  }
   if (nsplit > 1) {
     const long long nrows = (long long)a->B * a->T * a->Hq;
     long long gb = (nrows * 64 + 255) / 256;
     if (gb > 4096) gb = 4096;
-    if (nsplit > 16) hipLaunchKernelGGL(swa_combine_wide_kernel, dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
-    else if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
-    else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
-    else hipLaunchKernelGGL((swa_combine_kernel<16>), dim3((int)gb), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit);
+    if (append_blocks > 0) ap.first_block = (int)gb;
+    const dim3 cg((int)gb + append_blocks);
+    if (nsplit > 16) hipLaunchKernelGGL(swa_combine_wide_kernel, cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else hipLaunchKernelGGL((swa_combine_kernel<16>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
     rc = check_launch("ivl_swa_fwd(combine)");
+  } else if (append_blocks > 0) {
+    ap.first_block = 0;
+    hipLaunchKernelGGL(swa_cache_append_kernel, dim3(append_blocks), dim3(256), 0, st, ap);
+    rc = check_launch("ivl_swa_fwd(append)");
   }
   return rc;
 }
@@ -1373,9 +1413,11 @@ extern "C" int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_
   long long items = (long long)B * nt * Hkv * (SWA_D / 8);
   long long gb = (items + 255) / 256;
   if (gb > 2048) gb = 2048;
-  hipLaunchKernelGGL(swa_cache_append_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)k_new, (const bf16_t*)v_new, (long long)kn_sb, (long long)kn_st, (long long)kn_sh,
-                     (bf16_t*)k_cache, (bf16_t*)v_cache, B, T, Hkv, cache_capacity, (long long)pos, (const long long*)pos_dev,
-                     (const bf16_t*)rope_cos, (const bf16_t*)rope_sin, rope_s0, rope_s1);
+  AppendArgs ap;
+  ap.k_new = (const bf16_t*)k_new; ap.v_new = (const bf16_t*)v_new; ap.kn_sb = kn_sb; ap.kn_st = kn_st; ap.kn_sh = kn_sh;
+  ap.k_cache = (bf16_t*)k_cache; ap.v_cache = (bf16_t*)v_cache; ap.B = B; ap.T = T; ap.Hkv = Hkv; ap.C = cache_capacity;
+  ap.pos = (long long)pos; ap.pos_dev = (const long long*)pos_dev;
+  ap.rcos = (const bf16_t*)rope_cos; ap.rsin = (const bf16_t*)rope_sin; ap.rs0 = rope_s0; ap.rs1 = rope_s1; ap.first_block = 0;
+  hipLaunchKernelGGL(swa_cache_append_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream, ap);
   return check_launch("ivl_swa_cache_append");
 }

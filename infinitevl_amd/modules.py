@@ -271,14 +271,19 @@ class GatedDeltaNet(nn.Module):
                                    recurrent_state=layer.recurrent_state,
                                    cache_kwargs={"op": "set", "delta_len": T, "cache_position": cache_position})
             return ops.linear(o, self.o_proj.weight, self.o_proj.bias), None
-        q, k, v, g, beta = ops.gdn_prologue(
-            proj, (cq, ck, cv, ca, cb), (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight),
-            prev, outs, A32, dt32, H, Dq, Dk, Dv)
-        fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
-        extra = {"mma_dtype": self.mma_dtype} if mode == "chunk" else {}
-        o, _ = fn(q=q.view(B, T, H, K), k=k.view(B, T, self.num_key_value_heads, K), v=v.view(B, T, H, V), g=g,
-                  beta=beta, initial_state=h0, use_qk_l2norm_in_kernel=True,
-                  final_state_out=layer.recurrent_state if layer is not None else None, **extra)
+        convs = (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight)
+        if mode == "chunk" and Dk == Dq and K == 128 and V == 256 and convs[0].shape[-1] == 4:
+            # convs + gates inside the chunk kernel's pre-pass: q / k / v / g / beta never reach HBM, one launch less
+            o = ops.gdn_chunk_fused(proj, (cq, ck, cv, ca, cb), convs, prev, outs, A32, dt32, H, K, V,
+                                    initial_state=h0, final_state_out=layer.recurrent_state if layer is not None else None,
+                                    mma_dtype=self.mma_dtype)
+        else:
+            q, k, v, g, beta = ops.gdn_prologue(proj, (cq, ck, cv, ca, cb), convs, prev, outs, A32, dt32, H, Dq, Dk, Dv)
+            fn = ops.chunk_gated_delta_rule if mode == "chunk" else ops.fused_recurrent_gated_delta_rule
+            extra = {"mma_dtype": self.mma_dtype} if mode == "chunk" else {}
+            o, _ = fn(q=q.view(B, T, H, K), k=k.view(B, T, self.num_key_value_heads, K), v=v.view(B, T, H, V), g=g,
+                      beta=beta, initial_state=h0, use_qk_l2norm_in_kernel=True,
+                      final_state_out=layer.recurrent_state if layer is not None else None, **extra)
         if layer is not None:                                                          # std:1325-1333
             past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
                                    recurrent_state=layer.recurrent_state,

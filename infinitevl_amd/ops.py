@@ -188,6 +188,36 @@ def chunk_gated_delta_rule(
     return (o.transpose(1, 2) if head_first else o), ht
 
 
+def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv_states_out, A_log32, dt_bias32,
+                    H: int, K: int, V: int, scale=None, initial_state=None, final_state_out=None, mma_dtype=None):
+    """Chunked gated delta rule with its front end (3 short convs + SiLU + gate math) inside the pre-pass: one call from
+    the fused projection output to the mixer core's output (std:1253-1323).  proj [B,T,ld] bf16; cols = (col_q, col_k,
+    col_v, col_a, col_b); conv_weights 3 x [D,1,4] bf16; conv_states_in / _out 3 x ([B,D,4] bf16 or None; out may alias in).
+    Returns o [B,T,H,V] bf16; the final recurrent state is written into `final_state_out` when given."""
+    _need_gpu(proj)
+    B, T, ld = proj.shape
+    assert proj.is_contiguous() and proj.dtype == torch.bfloat16
+    lib = _lib.load()
+    nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, T, H, K, V)
+    if nbytes == 0:
+        raise ValueError(f"gdn_chunk_fused: unsupported head shape K={K}, V={V} (built for 128/256)")
+    ws = get_workspace(nbytes, proj.device, "gdn")
+    o = torch.empty(B, T, H, V, dtype=torch.bfloat16, device=proj.device)
+    h0, ht = initial_state, final_state_out
+    for s in (h0, ht):
+        if s is not None:
+            assert s.is_contiguous() and tuple(s.shape) == (B, H, K, V), (s.shape, (B, H, K, V))
+    wq, wk, wv = conv_weights
+    si, so = conv_states_in, conv_states_out
+    _lib.check(lib.ivl_gdn_chunk_fused_fwd(
+        _p(proj), ld, cols[0], cols[1], cols[2], cols[3], cols[4], _p(wq), _p(wk), _p(wv),
+        _p(si[0]), _p(si[1]), _p(si[2]), _p(so[0]), _p(so[1]), _p(so[2]), _p(A_log32), _p(dt_bias32), _p(o),
+        _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32, _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
+        B, T, H, K, V, wq.shape[-1], float(K ** -0.5 if scale is None else scale), mma_code(mma_dtype), _p(ws), ws.numel(),
+        _stream(proj)))
+    return o
+
+
 def gdn_gate(a: torch.Tensor, b: torch.Tensor, A_log: torch.Tensor, dt_bias: torch.Tensor):
     """g = -exp(A_log) * softplus(a + dt_bias) (fp32), beta = sigmoid(b) (bf16); std:1293-1294.
     a, b are the a_proj / b_proj outputs [..., H] in bf16."""
@@ -449,7 +479,7 @@ def swa_forward(
     q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, *, window: Optional[int], scaling: float,
     k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
     pos: int = 0, pos_dev: Optional[torch.Tensor] = None, n_query: Optional[int] = None,
-    layout: str = "bthd", mma_dtype=None, rope=None,
+    layout: str = "bthd", mma_dtype=None, rope=None, append: bool = False,
 ) -> torch.Tensor:
     """Sliding-window GQA attention over (ring cache ++ new keys); returns o [B,T,Hq,d] bf16.
 
@@ -457,7 +487,9 @@ def swa_forward(
     (any strides with a contiguous last dim are accepted -- no copies are made).
     `n_query` = T (defaults to q's length); T_new >= T, the first T_new-T new keys being older keys.
     `rope=(cos, sin, mrope_section)` (cos/sin bf16 [3,B,T,d]): q and k_new are the UN-rotated projections and M-RoPE
-    (std:949-984) is applied while they are loaded -- bit-identical to apply_mrope_inplace followed by this call."""
+    (std:949-984) is applied while they are loaded -- bit-identical to apply_mrope_inplace followed by this call.
+    `append=True`: the call's tokens are also appended to the ring afterwards (swa_cache_append's work, folded into the
+    split-KV combine launch when there is one)."""
     _need_gpu(q, k_new, v_new, k_cache, v_cache, pos_dev)
     if q.dtype != torch.bfloat16 or k_new.dtype != torch.bfloat16 or v_new.dtype != torch.bfloat16:
         raise ValueError("swa_forward is built for bf16")
@@ -494,6 +526,7 @@ def swa_forward(
     a.scaling = float(scaling)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     a.mma_dtype = mma_code(mma_dtype)
+    a.append_new = int(bool(append) and C > 0)
     if rope is not None:
         cos, sin, sec = _rope_args(rope, B, T, d)
         a.rope_cos, a.rope_sin, a.rope_s0, a.rope_s1 = cos.data_ptr(), sin.data_ptr(), int(sec[0]), int(sec[1])

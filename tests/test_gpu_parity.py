@@ -1231,3 +1231,37 @@ def test_full_attention_layer_with_dynamic_cache_equals_one_causal_call():
     assert cache.get_seq_length() == 150
     got = torch.cat([a, b], 1)
     assert rms_rel(full.float().cpu(), got.float().cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("B,T,hist,st_dtype", [(1, 256, True, torch.bfloat16), (2, 130, False, torch.float32), (1, 65, True, torch.float32),
+                                              (1, 3, True, torch.bfloat16), (1, 1000, True, torch.bfloat16)])
+def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
+    """the pre-pass that applies the three short convs (+SiLU, carry-in / carry-out) and the gate math
+    itself (ivl_gdn_chunk_fused_fwd) must equal ivl_gdn_prologue_fwd followed by ivl_gdn_chunk_fwd bit for bit: outputs,
+    final recurrent state and the three new conv states, with and without history, ragged T, T below the conv width."""
+    from infinitevl_amd import ops
+    H, K, V = 16, 128, 256
+    Dq, Dk, Dv = H * K, H * K, H * V
+    g_ = torch.Generator(device=DEV).manual_seed(B * 1000 + T)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)          # q | k | v | gate (unused here) | a | b
+    ld = cols[4] + H
+    proj = rn(B, T, ld)
+    cw = [rn(D_, 1, 4) * 0.5 for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.randn(H, device=DEV, generator=g_), torch.randn(H, device=DEV, generator=g_)
+    cs = [rn(B, D_, 4) if hist else None for D_ in (Dq, Dk, Dv)]
+    h0 = (torch.randn(B, H, K, V, device=DEV, generator=g_) * 0.1).to(st_dtype) if hist else None
+    # unfused
+    so1 = [torch.zeros(B, D_, 4, dtype=torch.bfloat16, device=DEV) for D_ in (Dq, Dk, Dv)]
+    q, k, v, g, beta = ops.gdn_prologue(proj, cols, cw, cs, so1, A32, dt32, H, Dq, Dk, Dv)
+    ht1 = torch.zeros(B, H, K, V, dtype=st_dtype, device=DEV)
+    o1, _ = ops.chunk_gated_delta_rule(q.view(B, T, H, K), k.view(B, T, H, K), v.view(B, T, H, V), g, beta, initial_state=h0,
+                                       use_qk_l2norm_in_kernel=True, final_state_out=ht1)
+    # fused (conv states updated IN PLACE when there is history: out aliases in)
+    so2 = [c.clone() for c in cs] if hist else [torch.zeros(B, D_, 4, dtype=torch.bfloat16, device=DEV) for D_ in (Dq, Dk, Dv)]
+    ht2 = torch.zeros(B, H, K, V, dtype=st_dtype, device=DEV)
+    o2 = ops.gdn_chunk_fused(proj, cols, cw, so2 if hist else cs, so2, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht2)
+    assert torch.equal(o1, o2)
+    assert torch.equal(ht1, ht2)
+    for a, b_ in zip(so1, so2):
+        assert torch.equal(a, b_)
