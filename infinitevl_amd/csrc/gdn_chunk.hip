@@ -717,15 +717,19 @@ __device__ __forceinline__ void dma1(const unsigned char* gsrc, unsigned int lds
 // workgroup barrier that waits for this wave's LDS traffic only (no vector-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The two loader waves take the 4 KB DMA units of a half image alternately (unit u -> loader u & 1):
+// The SCAN_NL loader waves take the 4 KB DMA units of a half image round-robin (unit u -> loader u % SCAN_NL).  A DMA
+// instruction costs its wave ~50-100 cycles of issue time and a chunk takes 15 units = 60 instructions: with two loaders
+// (30 each) the loaders arrived last at the M barrier (state waves waited ~400 cycles per chunk there, ~240 with four).
 //   H1(ci): Wn | q_hat (contiguous: 8 units in bf16, 4 in fp8), the workgroup's u slab (NCW / 2 units), + 1 piece e^gamma (loader 0)
 //   H2(ci): Kd^T | Aqk (contiguous: 6 units in bf16, 3 in fp8)
 __host__ __device__ constexpr int h1_units(int ncw, bool f8) { return (f8 ? 4 : 8) + ncw / 2; }
 __host__ __device__ constexpr int h2_units(bool f8) { return f8 ? 3 : 6; }
+constexpr int SCAN_NL = 4;
+__host__ __device__ constexpr int units_of(int L, int n) { return (n - L + SCAN_NL - 1) / SCAN_NL; }   // units u < n with u % SCAN_NL == L
 __host__ __device__ constexpr int loader_n1(int L, int ncw, bool f8) {       // pieces of H1 issued by loader L
-  return 4 * (L == 0 ? (h1_units(ncw, f8) + 1) / 2 : h1_units(ncw, f8) / 2) + (L == 0 ? 1 : 0);
+  return 4 * units_of(L, h1_units(ncw, f8)) + (L == 0 ? 1 : 0);
 }
-__host__ __device__ constexpr int loader_n2(int L, bool f8) { return 4 * (L == 0 ? (h2_units(f8) + 1) / 2 : h2_units(f8) / 2); }
+__host__ __device__ constexpr int loader_n2(int L, bool f8) { return 4 * units_of(L, h2_units(f8)); }
 
 template <int L, int NCW, bool F8>
 __device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, int slab_wg, unsigned int lane16) {
@@ -733,10 +737,10 @@ __device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int i
   constexpr int NA = F8 ? 4 : 8;                   // units of Wn | q_hat
 #pragma unroll
   for (int u = 0; u < NA; ++u)
-    if ((u & 1) == L) dma4(rec + R::WN + u * 4096, img + (unsigned int)(R::WN + u * 4096), lane16);
+    if (u % SCAN_NL == L) dma4(rec + R::WN + u * 4096, img + (unsigned int)(R::WN + u * 4096), lane16);
 #pragma unroll
   for (int u = 0; u < NCW / 2; ++u)
-    if (((NA + u) & 1) == L) dma4(rec + R::U + slab_wg * (NCW * 2048) + u * 4096, img + (unsigned int)(Img<F8>::U + u * 4096), lane16);
+    if ((NA + u) % SCAN_NL == L) dma4(rec + R::U + slab_wg * (NCW * 2048) + u * 4096, img + (unsigned int)(Img<F8>::U + u * 4096), lane16);
   if (L == 0) dma1(rec + R::EG, img + (unsigned int)R::EG, lane16);
 }
 template <int L, bool F8>
@@ -744,7 +748,7 @@ __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int i
   using R = Rec<F8>;
 #pragma unroll
   for (int u = 0; u < h2_units(F8); ++u)
-    if ((u & 1) == L) dma4(rec + R::KDT + u * 4096, img + (unsigned int)(R::KDT + u * 4096), lane16);
+    if (u % SCAN_NL == L) dma4(rec + R::KDT + u * 4096, img + (unsigned int)(R::KDT + u * 4096), lane16);
 }
 
 // Barrier protocol (every wave of the workgroup executes the same sequence P, T(0), M(0), T(1), M(1), ...):
@@ -787,7 +791,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   }
 }
 
-// Workgroup = NCW state waves + NCW output waves + 2 loader waves; pair w owns state columns v0..v0+15.
+// Workgroup = NCW state waves + NCW output waves + SCAN_NL (4) loader waves; pair w owns state columns v0..v0+15.
 //   state wave  : S (accumulators), per chunk  sb = bf16(S) -> LDS | T | v_new = u + Wn sb -> LDS | M | S = egl S + Kd^T v_new
 //   output wave : per chunk                                         T | (q_hat sb)^T e^gamma    | M | + v_new^T Aqk^T, store o
 // A single wave issues at most one instruction per ~4-5 cycles, and a chunk needs ~290 of them per slab: split over two
@@ -818,7 +822,7 @@ __device__ __forceinline__ typename FragT<F8>::type to_frag(f32x4 lo, f32x4 hi) 
 }
 
 template <int NCW, bool F8>
-__global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
+__global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL)) void gdn_chunk_scan_kernel(
     const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
     int T, int H, int t_seg0, int nt_seg, float scale) {
@@ -845,8 +849,11 @@ __global__ __launch_bounds__(64 * (2 * NCW + 2)) void gdn_chunk_scan_kernel(
   const unsigned char* ws_bh = ws + (size_t)bh * nt_seg * R::STRIDE;
 
   if (wave_u >= 2 * NCW) {                                      // ---- loader waves ----
+    static_assert(SCAN_NL == 4, "loader dispatch below");
     if (wave_u == 2 * NCW) scan_loader<0, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
-    else scan_loader<1, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    else if (wave_u == 2 * NCW + 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    else if (wave_u == 2 * NCW + 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    else scan_loader<3, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
     return;
   }
   const int pair = wave_u < NCW ? wave_u : wave_u - NCW;
@@ -1097,10 +1104,10 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
     if (ncw == 2)
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2, F8>), dim3(B * H, 8), dim3(384), scan_lds_bytes(2, F8), st, (const unsigned char*)wsb,
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2, F8>), dim3(B * H, 8), dim3(64 * (4 + SCAN_NL)), scan_lds_bytes(2, F8), st, (const unsigned char*)wsb,
                          (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     else
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4, F8>), dim3(B * H, 4), dim3(640), scan_lds_bytes(4, F8), st, (const unsigned char*)wsb,
+      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4, F8>), dim3(B * H, 4), dim3(64 * (8 + SCAN_NL)), scan_lds_bytes(4, F8), st, (const unsigned char*)wsb,
                          (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
