@@ -252,7 +252,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
     }
   } else {
-    const bf16_t* xb = pf.proj + (size_t)b * T * pf.ld;              // row t at xb + t * ld
+    const bf16_t* xb = pf.proj + (size_t)b * T * pf.ld;              // row t at xb + t * ld (32-bit element offsets: host-checked)
+    const unsigned int ld32 = (unsigned int)pf.ld;
     // rows of a run of NR tokens starting at chunk row `first`: global times t0 + first - 3 .. t0 + first + NR - 1,
     // clamped into the sequence (times < 0 come from the conv state, rows past the end are zeroed downstream)
     auto load_run = [&](u32x4* xr, int first, auto nr_tag, int col) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       for (int kk = 0; kk < NR + 3; ++kk) {
         int tg = t0 + first - 3 + kk;
         tg = tg < 0 ? 0 : (tg > T - 1 ? T - 1 : tg);
-        xr[kk] = *(const u32x4*)(xb + (size_t)tg * pf.ld + col);
+        xr[kk] = *(const u32x4*)(xb + ((unsigned int)tg * ld32 + (unsigned int)col));
       }
     };
     // the history of a run that starts at time 0 is the conv state: state[c][1..3] = times -3, -2, -1
@@ -286,34 +287,35 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
     };
     // new conv state = the last four inputs of the sequence ([old state, x] when T < 4): written by the thread that read
-    // the old one (chunk 0, run 0), so that st_out may alias st_in
-    auto put_state = [&](const u32x4* hist3, bf16_t* st_out, const bf16_t* st_in, int col, int dch) {
-      if (st_out == nullptr) return;
-      const int D = H * (dch == 2 ? GV : GK), d0 = h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct);
-      unsigned int ns[8][4];
+    // the old one (chunk 0, run 0), so that st_out may alias st_in.  tail_load issues the four row loads together with the
+    // run's own loads (four dependent round trips otherwise, on the workgroup every other one waits for).
+    auto tail_load = [&](u32x4* tail, int col) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int e = T + j;                                           // index into ext = [state(4), x(T)]
-        u32x4 xv = u32x4{0u, 0u, 0u, 0u};
-        if (e >= 4) xv = *(const u32x4*)(xb + (size_t)(e - 4) * pf.ld + col);
-        const unsigned int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          unsigned int val = (c & 1) ? xs[c >> 1] >> 16 : xs[c >> 1] & 0xffffu;
-          if (e < 4) {                                                 // e in 1..3 (T = 1..3... never 0: T >= 1): old state[c][e]
-            const u32x4 hx = e == 1 ? hist3[0] : (e == 2 ? hist3[1] : hist3[2]);
-            const unsigned int hs[4] = {hx.x, hx.y, hx.z, hx.w};
-            val = (c & 1) ? hs[c >> 1] >> 16 : hs[c >> 1] & 0xffffu;
-          }
-          ns[c][j] = val;
-        }
+        int tg = T - 4 + j;                                            // ext[T + j] with ext = [state(4), x(T)]
+        tg = tg < 0 ? 0 : tg;
+        tail[j] = *(const u32x4*)(xb + ((unsigned int)tg * ld32 + (unsigned int)col));
       }
-      (void)st_in;
+    };
+    auto put_state = [&](const u32x4* tail, const u32x4* hist3, bf16_t* st_out, int dch) {
+      if (st_out == nullptr) return;
+      const int D = H * (dch == 2 ? GV : GK), d0 = h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct);
+      u32x4 row[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = T + j;                                           // e >= 4: x[e - 4]; e = 1..3 (T < 4): old state[.][e]
+        row[j] = e >= 4 ? tail[j] : (e == 1 ? hist3[0] : (e == 2 ? hist3[1] : hist3[2]));
+      }
+      // row[j] holds (channel 0..7) of ext[T + j]; the state is [channel][4 taps]: transpose 4 x 8 halfwords
+      const unsigned int r0w[4] = {row[0].x, row[0].y, row[0].z, row[0].w}, r1w[4] = {row[1].x, row[1].y, row[1].z, row[1].w};
+      const unsigned int r2w[4] = {row[2].x, row[2].y, row[2].z, row[2].w}, r3w[4] = {row[3].x, row[3].y, row[3].z, row[3].w};
       u32x4* op = (u32x4*)(st_out + ((size_t)b * D + d0) * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        op[i] = u32x4{ns[2 * i][0] | (ns[2 * i][1] << 16), ns[2 * i][2] | (ns[2 * i][3] << 16),
-                      ns[2 * i + 1][0] | (ns[2 * i + 1][1] << 16), ns[2 * i + 1][2] | (ns[2 * i + 1][3] << 16)};
+      for (int i = 0; i < 4; ++i) {                                    // channels 2i, 2i + 1
+        const unsigned int lo01 = (r0w[i] & 0xffffu) | (r1w[i] << 16), lo23 = (r2w[i] & 0xffffu) | (r3w[i] << 16);
+        const unsigned int hi01 = (r0w[i] >> 16) | (r1w[i] & 0xffff0000u), hi23 = (r2w[i] >> 16) | (r3w[i] & 0xffff0000u);
+        op[i] = u32x4{lo01, lo23, hi01, hi23};
+      }
     };
     const bool own_state = t0 == 0;                                    // this workgroup holds time 0
     if (wave_u < 4) {
@@ -328,14 +330,17 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {                                 // beta = bf16(sigmoid(b)) (std:1293)
         const int tg = min(t0 + 4 * r0 + rr, T - 1);
-        const float bv = bf2f(xb[(size_t)tg * pf.ld + pf.col_b + h]);
-        braw[rr] = f2bf(1.0f / (1.0f + expf(-bv)));
+        const float bv = bf2f(xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)]);
+        braw[rr] = f2bf(sigmoidf_(bv));
       }
       if (own_state && r0 == 0) {
+        u32x4 tq[4], tk[4];
+        tail_load(tq, cq);
+        tail_load(tk, ck);
         history(xq, pf.st_in[0], 0);
         history(xk, pf.st_in[1], 1);
-        put_state(xq, pf.st_out[0], pf.st_in[0], cq, 0);
-        put_state(xk, pf.st_out[1], pf.st_in[1], ck, 1);
+        put_state(tq, xq, pf.st_out[0], 0);
+        put_state(tk, xk, pf.st_out[1], 1);
       }
       conv4_silu<4>(xq, wq, qraw);
       conv4_silu<4>(xk, wk, kraw);
@@ -347,8 +352,10 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) wv[i] = wvp[i];
       if (own_state && vr == 0) {
+        u32x4 tv[4];
+        tail_load(tv, cv);
         history(xv, pf.st_in[2], 2);
-        put_state(xv, pf.st_out[2], pf.st_in[2], cv, 2);
+        put_state(tv, xv, pf.st_out[2], 2);
       }
       conv4_silu<8>(xv, wv, vraw);
     }
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const float bv = bf2f(row[pf.col_b + h]);
       const float sp = av > 20.f ? av : log1pf(expf(av));
       g_ld = -expf(pf.A_log[h]) * sp;
-      b_ld = bf2f(f2bf(1.0f / (1.0f + expf(-bv))));
+      b_ld = bf2f(f2bf(sigmoidf_(bv)));
     } else {
       g_ld = g[tok];
       b_ld = bf2f(beta[tok]);
@@ -1148,6 +1155,9 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
   IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
   IVL_REQUIRE(K == GK && V == GV && conv_width == 4, IVL_ERR_UNSUPPORTED,
               "ivl_gdn_chunk_fused_fwd: built for K=128, V=256, conv width 4 (got %d,%d,%d)", K, V, conv_width);
+  IVL_REQUIRE((long long)T * ld < (1LL << 31), IVL_ERR_UNSUPPORTED,
+              "ivl_gdn_chunk_fused_fwd: T * ld = %lld elements exceeds the 32-bit row addressing of the pre-pass (split the call)",
+              (long long)T * ld);
   IVL_REQUIRE(ld % 8 == 0 && col_q % 8 == 0 && col_k % 8 == 0 && col_v % 8 == 0 && col_q >= 0 && col_k >= 0 && col_v >= 0 &&
                   col_a >= 0 && col_b >= 0 && col_a + H <= ld && col_b + H <= ld,
               IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: projection columns must be 16-byte aligned and inside the row (ld=%lld)",

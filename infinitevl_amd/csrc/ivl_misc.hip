@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gdn_gate_kernel(
     const float av = bf2f(a[i]) + dt_bias[h];
     const float sp = av > 20.f ? av : log1pf(expf(av));
     g[i] = -expf(A_log[h]) * sp;
-    beta[i] = f2bf(1.0f / (1.0f + expf(-bf2f(b[i]))));
+    beta[i] = f2bf(sigmoidf_(bf2f(b[i])));
   }
 }
 

@@ -21,6 +21,14 @@ trace = torch.zeros(64, dtype=torch.int64, device=dev)
 lib.ivl_debug_set_trace.argtypes = [ctypes.c_void_p]
 run = lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True,
                                          final_state_out=state)
+if os.environ.get("IVL_TRACE_FUSED"):          # the pre-pass with the conv / gate front end (developer tool only)
+    Dq, Dk, Dv = H * K, H * K, H * V
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+    proj = rn(B, T, cols[4] + H)
+    cw = [rn(D_, 1, 4) for D_ in (Dq, Dk, Dv)]
+    cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.randn(H, device=dev, generator=g_), torch.randn(H, device=dev, generator=g_)
+    run = lambda: ops.gdn_chunk_fused(proj, cols, cw, cs, cs, A32, dt32, H, K, V, initial_state=state, final_state_out=state)
 for it in range(5):
     run()
 torch.cuda.synchronize()
