@@ -241,9 +241,9 @@ def pmc_traffic(kernel_name, chunk, window):
         return None
     k = json.load(open(files[-1]))["kernels"]
     want = {
-        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
+        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
         "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, true>", 32768),
-                                                      ("ivl::gdn_chunk_scan_kernel<2, false>", 49152)],
+                                                      ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
         "swa_prefill": [("ivl::swa_prefill_kernel", 196608), ("ivl::swa_combine_kernel<8>", 262144)],
         "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],

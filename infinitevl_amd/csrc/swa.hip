@@ -84,6 +84,21 @@ __device__ __forceinline__ float group_sum(float x) {
 // cos/sin: [3, B, T, 128] bf16 tables (t, h, w); the channel block selects its table by the mrope sections (s0 | s1 | rest,
 // multiples of 8).  Products and the sum are each rounded to bf16 like the reference's eager bf16 arithmetic: bit-identical
 // to ivl_mrope_fwd.  `row_off` = (b * T + t) * 128, `plane` = B * T * 128.
+// the arithmetic of rope_pair on tables already in registers
+__device__ __forceinline__ void rope_apply(u32x4& lo, u32x4& hi, const u32x4 c1, const u32x4 n1, const u32x4 c2, const u32x4 n2) {
+  const unsigned int x1[4] = {lo.x, lo.y, lo.z, lo.w}, x2[4] = {hi.x, hi.y, hi.z, hi.w};
+  const unsigned int cc1[4] = {c1.x, c1.y, c1.z, c1.w}, nn1[4] = {n1.x, n1.y, n1.z, n1.w};
+  const unsigned int cc2[4] = {c2.x, c2.y, c2.z, c2.w}, nn2[4] = {n2.x, n2.y, n2.z, n2.w};
+  unsigned int o1[4], o2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = bflo(x1[i]), a1 = bfhi(x1[i]), b0 = bflo(x2[i]), b1 = bfhi(x2[i]);
+    o1[i] = pack2bf(bf_round(a0 * bflo(cc1[i])) + bf_round(-b0 * bflo(nn1[i])), bf_round(a1 * bfhi(cc1[i])) + bf_round(-b1 * bfhi(nn1[i])));
+    o2[i] = pack2bf(bf_round(b0 * bflo(cc2[i])) + bf_round(a0 * bflo(nn2[i])), bf_round(b1 * bfhi(cc2[i])) + bf_round(a1 * bfhi(nn2[i])));
+  }
+  lo = u32x4{o1[0], o1[1], o1[2], o1[3]};
+  hi = u32x4{o2[0], o2[1], o2[2], o2[3]};
+}
 __device__ __forceinline__ void rope_pair(u32x4& lo, u32x4& hi, const bf16_t* cosp, const bf16_t* sinp, long long plane,
                                           long long row_off, int c0, int s0, int s1) {
   const int sec = c0 < s0 ? 0 : (c0 < s0 + s1 ? 1 : 2);
@@ -641,6 +656,31 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
           *(u32x4*)(smem + PF_V_OFF + st * PF_V_BYTES + (row0 + 8 * i) * PF_VSTRIDE + (L & 15) * 16) = r[i];
       }
     };
+    // tile of 64 un-rotated keys of this call (fused M-RoPE, K loaders only): the 8 key pieces and the 16 cos / sin pieces of
+    // the lane's four rows are requested together (one memory round trip), rotated and stored
+    auto rope_tile_store = [&](int kt, int st) {
+      const int kc = L & 7, row0 = L >> 3;
+      const int jn0 = kt * SWA_KT - n_ring + row0;                     // index among the call's keys, rows jn0 + 16 i
+      u32x4 lo[4], hi[4], c1[4], n1[4], c2[4], n2[4];
+      const int c0 = kc * 8;
+      const int sec = c0 < p.rs0 ? 0 : (c0 < p.rs0 + p.rs1 ? 1 : 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned int ko = (unsigned int)(jn0 + 16 * i) * kn_st32 + c0;
+        lo[i] = *(const u32x4*)(b_new + ko);
+        hi[i] = *(const u32x4*)(b_new + (ko + 64));
+        const long long off = sec * rplane + (long long)(jn0 + 16 * i) * SWA_D + c0;
+        c1[i] = *(const u32x4*)(rope_cos + off); n1[i] = *(const u32x4*)(rope_sin + off);
+        c2[i] = *(const u32x4*)(rope_cos + off + 64); n2[i] = *(const u32x4*)(rope_sin + off + 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rope_apply(lo[i], hi[i], c1[i], n1[i], c2[i], n2[i]);
+        unsigned char* rowp = smem + st * PF_K_BYTES + (row0 + 16 * i) * PF_KSTRIDE + kc * 16;
+        *(u32x4*)rowp = lo[i];
+        *(u32x4*)(rowp + 128) = hi[i];
+      }
+    };
     // tile i of the workgroup's range into stage i % 3, in two parts (part 0: the first PF_H1 DMA instructions, or the whole
     // tile when it takes the register path; part 1: the rest); returns true when part 0 issued DMA instructions
     constexpr int PF_H1 = 5;
@@ -653,7 +693,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
         else dma_tile(kt_begin + i, st, rf, PF_H1, nch);
         return true;
       }
-      if (part == 0) slow_store(kt_begin + i, st);
+      if (part == 0) {
+        const int j0 = (kt_begin + i) * SWA_KT;
+        if (is_k && p.rcos != nullptr && j0 >= n_ring && j0 + SWA_KT <= S) rope_tile_store(kt_begin + i, st);
+        else slow_store(kt_begin + i, st);
+      }
       return false;
     };
     // everything issued before part 0 of the newest tile (`newest_dma`: its PF_H1 instructions may stay in flight) has landed
@@ -1259,12 +1303,10 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
 // stand-alone ring append (ivl_swa_cache_append, and ivl_swa_fwd with append_new when no combine launch follows)
 __global__ __launch_bounds__(256) void swa_cache_append_kernel(AppendArgs ap) { ring_append(ap, blockIdx.x, gridDim.x); }
 
-// 16-row query groups per wave.  128-row workgroups halve the LDS traffic per MFMA (1.4x per-tile efficiency) but
-// also halve the number of workgroups: they pay once a call still offers >= 4 workgroups per CU (B*T*Hq >= 128K rows);
-// below that the finer 64-row granularity balances the causal triangle better (measured: T=4096 118 vs 132 us).
-static int swa_qg(int B, int T, int Hq) { return (long long)B * T * Hq >= 131072 ? 2 : 1; }
+// The 64-row kernel (QG = 1) serves decode / T <= 64 calls; longer calls run swa_prefill_kernel (the QG = 2 instantiation of
+// round 2a - two 16-row groups per wave - is superseded by it and no longer launched).
+static int swa_qg(int, int, int) { return 1; }
 
-// prefill kernel (128-row workgroups of 512 threads, one per CU) for every call with more than 64 query rows per head
 static int swa_base_nsplit(int B, int T, int Hq) {
   if (T > SWA_QT) {
     const long long base = (long long)B * ((T + PF_QT - 1) / PF_QT) * Hq;
@@ -1363,7 +1405,6 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
     hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
   else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);
-  else if (qg == 2) hipLaunchKernelGGL((swa_fwd_kernel<false, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p);
   int rc = check_launch("ivl_swa_fwd");
   if (rc != IVL_OK) return rc;

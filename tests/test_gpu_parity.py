@@ -376,8 +376,8 @@ def test_swa_band_indices_bit_exact(W, seen, T):
 
 
 def test_swa_128_row_workgroups_equal_64_row_workgroups():
-    """Large calls (B*T*Hq >= 128K rows) run the variant with two 16-row query groups per wave; a row's tiles
-    and their order are the same in both variants, so a batched call must equal the per-sequence calls bit for bit."""
+    """Batched prefill call == the per-sequence calls bit for bit (a row's tiles and their order do not depend on the
+    grid: same 128-row workgroups of swa_prefill_kernel, different block order / XCD placement), ring wrap included."""
     from infinitevl_amd import ops
     B, T, Hq, Hkv, d, W = 2, 4096, 16, 2, 128, 1024
     C = W - 1
