@@ -197,6 +197,14 @@ IVL_API int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t k
                          int64_t pos, const int64_t* pos_dev, const void* rope_cos, const void* rope_sin,
                          int rope_s0, int rope_s1, void* stream);
 
+/* 3-D rotary tables cos / sin bf16 [rows, 2*half_dim] from position ids (int64 [rows], rows = 3*B*T in (axis, batch,
+ * token) order) and the inverse frequencies fp32 [half_dim]: cos(pos * inv_freq) in fp32, the frequencies repeated over
+ * both halves of the channels, times attention_scaling, rounded to bf16.
+ * Replaces InfiniteVLRotaryEmbedding.forward (std:896-930: cast, K=1 matmul, cat, cos, sin, scaling, cast) with one launch.
+ * `advance` is reserved (pass 0). */
+IVL_API int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int rows,
+                        int half_dim, float attention_scaling, int64_t advance, void* stream);
+
 /* *counter += delta on the device (graph-replayable position bookkeeping). */
 IVL_API int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);
 

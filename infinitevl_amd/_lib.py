@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "ivl_swa_workspace_bytes", "ivl_swa_fwd", "ivl_swa_cache_append", "ivl_counter_add",
     "ivl_gdn_prologue_fwd", "ivl_rmsnorm_swish_gate_strided_fwd", "ivl_mrope_strided_fwd",
     "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd", "ivl_linear_small_m_fwd",
-    "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd",
+    "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd", "ivl_rope_tables_fwd",
 )
 
 
@@ -80,6 +80,8 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_chunk_fused_fwd.restype = i
     lib.ivl_gdn_chunk_fused_fwd.argtypes = ([vp, c_int64, i, i, i, i, i] + [vp] * 9 + [vp, vp, vp, vp, i, vp, i] +
                                             [i, i, i, i, i, i, f, i, vp, sz, vp])
+    lib.ivl_rope_tables_fwd.restype = i
+    lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, c_int64, vp]
     lib.ivl_gdn_gate_fwd.restype = i
     lib.ivl_gdn_gate_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp]
     lib.ivl_short_conv_fwd.restype = i

@@ -247,6 +247,25 @@ __global__ __launch_bounds__(256) void mrope_kernel(
   }
 }
 
+// 3-D rotary tables (std:896-930): row r = one (axis, batch, token) position; cos / sin of position * inv_freq[j] in fp32,
+// the 64 frequencies repeated over both halves of the 128 channels (emb = cat(freqs, freqs)), scaled, rounded to bf16.
+// One launch instead of the eager chain (cast, outer product, cat, cos, sin, two scalings, two casts).
+__global__ __launch_bounds__(256) void rope_tables_kernel(const long long* __restrict__ pos, const float* __restrict__ inv_freq,
+                                                         bf16_t* __restrict__ cos_o, bf16_t* __restrict__ sin_o, int rows,
+                                                         int half_dim, float scaling) {
+  const long long total = (long long)rows * half_dim;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % half_dim);
+    const long long r = i / half_dim;
+    const float f = (float)pos[r] * inv_freq[j];
+    const bf16_t c = f2bf(cosf(f) * scaling), s_ = f2bf(sinf(f) * scaling);
+    cos_o[r * 2 * half_dim + j] = c;
+    cos_o[r * 2 * half_dim + half_dim + j] = c;
+    sin_o[r * 2 * half_dim + j] = s_;
+    sin_o[r * 2 * half_dim + half_dim + j] = s_;
+  }
+}
+
 __global__ void counter_add_kernel(long long* c, long long delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
 }
@@ -322,6 +341,21 @@ extern "C" int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
   hipLaunchKernelGGL(mrope_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)q, (bf16_t*)k, (const bf16_t*)cos, (const bf16_t*)sin, B, T, Hq, Hkv, d, s0, s1);
   return check_launch("ivl_mrope_fwd");
+}
+
+extern "C" int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int rows,
+                                   int half_dim, float attention_scaling, int64_t advance, void* stream) {
+  IVL_REQUIRE(position_ids && inv_freq && cos_out && sin_out, IVL_ERR_INVALID_ARG, "ivl_rope_tables_fwd: NULL pointer");
+  IVL_REQUIRE(rows > 0 && half_dim > 0 && half_dim % 2 == 0, IVL_ERR_INVALID_ARG, "ivl_rope_tables_fwd: bad sizes rows=%d half_dim=%d",
+              rows, half_dim);
+  const long long total = (long long)rows * half_dim;
+  long long gb = (total + 255) / 256;
+  if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(rope_tables_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream, (const long long*)position_ids, inv_freq,
+                     (bf16_t*)cos_out, (bf16_t*)sin_out, rows, half_dim, attention_scaling);
+  int rc = check_launch("ivl_rope_tables_fwd");
+  (void)advance;
+  return rc;
 }
 
 extern "C" int ivl_counter_add(int64_t* counter, int64_t delta, void* stream) {

@@ -40,6 +40,9 @@ class InfiniteVLRotaryEmbedding(nn.Module):
     def forward(self, x: torch.Tensor, position_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._inv_freq.device != x.device:
             self._inv_freq = self._inv_freq.to(x.device)
+        if x.is_cuda and x.dtype == torch.bfloat16:
+            # one launch instead of the eager chain (cast, outer product, cat, cos, sin, scalings, casts)
+            return ops.rope_tables(position_ids, self._inv_freq, self.attention_scaling)
         # outer product position x frequency in fp32 (std:920-925 does it as a K=1 matmul)
         freqs = position_ids[..., None].float() * self._inv_freq
         emb = torch.cat((freqs, freqs), dim=-1)

@@ -218,6 +218,18 @@ def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv
     return o
 
 
+def rope_tables(position_ids: torch.Tensor, inv_freq: torch.Tensor, attention_scaling: float = 1.0):
+    """cos / sin tables bf16 [..., 2 * len(inv_freq)] of int64 position ids (any leading shape) in one launch (std:896-930)."""
+    _need_gpu(position_ids, inv_freq)
+    pos = position_ids if position_ids.dtype == torch.int64 and position_ids.is_contiguous() else position_ids.to(torch.int64).contiguous()
+    half = inv_freq.numel()
+    cos = torch.empty(*pos.shape, 2 * half, dtype=torch.bfloat16, device=pos.device)
+    sin = torch.empty_like(cos)
+    _lib.check(_lib.load().ivl_rope_tables_fwd(_p(pos), _p(inv_freq), _p(cos), _p(sin), pos.numel(), half,
+                                               float(attention_scaling), 0, _stream(pos)))
+    return cos, sin
+
+
 def gdn_gate(a: torch.Tensor, b: torch.Tensor, A_log: torch.Tensor, dt_bias: torch.Tensor):
     """g = -exp(A_log) * softplus(a + dt_bias) (fp32), beta = sigmoid(b) (bf16); std:1293-1294.
     a, b are the a_proj / b_proj outputs [..., H] in bf16."""

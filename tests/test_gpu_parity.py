@@ -1265,3 +1265,28 @@ def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
     assert torch.equal(ht1, ht2)
     for a, b_ in zip(so1, so2):
         assert torch.equal(a, b_)
+
+
+def test_rope_tables_kernel_matches_the_eager_chain():
+    """ivl_rope_tables_fwd == the reference's eager rotary chain (std:896-930) on the same positions: identical bf16 tables
+    (cos / sin in fp32 from the same fp32 product, rounded once), 3-D positions with distinct axes, large positions."""
+    from infinitevl_amd import ops
+    from infinitevl_amd.harness import InfiniteVLTextConfig
+    from infinitevl_amd.modules import InfiniteVLRotaryEmbedding
+    rot = InfiniteVLRotaryEmbedding(InfiniteVLTextConfig())
+    B, T = 2, 300
+    base = torch.tensor([0, 131072 - 17], device=DEV)[None, :, None]
+    pos = torch.stack([torch.arange(T), torch.arange(T) // 3, torch.arange(T) % 7]).to(DEV)[:, None, :] + base
+    inv = rot.inv_freq.to(DEV)
+    freqs = pos[..., None].float() * inv
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos_ref, sin_ref = bf(emb.cos()), bf(emb.sin())
+    cos, sin = ops.rope_tables(pos.contiguous(), inv)
+    assert cos.shape == (3, B, T, 128) and cos.dtype == torch.bfloat16
+    # the device cosf / sinf may differ from torch's by an fp32 ulp: at most one bf16 ulp on a handful of entries
+    for got, ref in ((cos, cos_ref), (sin, sin_ref)):
+        d = (got.float() - ref.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 1e-2, (float(d.max()), float((d > 0).float().mean()))
+    x = torch.zeros(1, dtype=torch.bfloat16, device=DEV)
+    c2, s2 = rot(x, pos)
+    assert torch.equal(c2, cos) and torch.equal(s2, sin)
