@@ -244,7 +244,7 @@ def pmc_traffic(kernel_name, chunk, window):
         "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
         "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, true>", 32768),
                                                       ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
-        "swa_prefill": [("ivl::swa_prefill_kernel", 196608), ("ivl::swa_combine_kernel<8>", 262144)],
+        "swa_prefill": [("ivl::swa_prefill_kernel", 196608), ("ivl::swa_combine_kernel<8, true>", 270336)],
         "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
         "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
         "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],

@@ -935,7 +935,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       const float mu = m == -INFINITY ? 0.f : m;
       const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
       const float l = l_run * a0 + l1 * a1;
-      const float inv = p.nsplit == 1 ? (l > 0.f ? 1.0f / l : 0.f) : 1.0f;
+      const float inv = l > 0.f ? 1.0f / l : 0.f;      // normalised rows also for the split-KV partials (stored in bf16)
       const float w0 = a0 * inv, w1 = a1 * inv;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -953,8 +953,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       }
     }
     __syncthreads();
-    // ---- whole-row stores by the 512 compute threads ----------------------------------------------------------------
-    if (p.nsplit == 1) {
+    // ---- whole-row stores by the 512 compute threads: 256 B of bf16 per row, into o or into the split's partial rows ----
+    {
+      bf16_t* const dst = p.nsplit == 1 ? p.o : (bf16_t*)p.part_o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;       // row, 8-channel piece
@@ -962,21 +963,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
         if (t < p.T) {
           const unsigned char* src = smem + r * PF_OSTRIDE + c * 32;
           const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
-          *(u32x4*)(p.o + (((long long)b * p.T + t) * p.Hq + hq) * SWA_D + 8 * c) =
+          const long long orow = p.nsplit == 1 ? ((long long)b * p.T + t) * p.Hq + hq
+                                               : (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
+          *(u32x4*)(dst + orow * SWA_D + 8 * c) =
               u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
         }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + 512 * i, r = idx >> 5, c = idx & 31;       // row, 4-channel piece
-        const int t = tile_row0 + r;
-        if (t < p.T) {
-          const long long prow = (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
-          *(f32x4*)(p.part_o + prow * SWA_D + 4 * c) = *(const f32x4*)(smem + r * PF_OSTRIDE + c * 16);
-        }
-      }
-      if (tid < PF_QT && tile_row0 + tid < p.T) {
+      if (p.nsplit > 1 && tid < PF_QT && tile_row0 + tid < p.T) {
         const long long prow = (((long long)b * p.nsplit + split) * p.T + tile_row0 + tid) * p.Hq + hq;
         *(float2*)(p.part_ml + prow * 2) = *(const float2*)(smem + PF_ML_OFF + tid * 8);
       }
@@ -1217,7 +1210,9 @@ __device__ __forceinline__ void ring_append(const AppendArgs& a, long long block
 
 // merge split-KV partials: one wavefront per (b, t, head) row, 2 d-values per lane; every split's loads are
 // issued before the first use (template on the split count so the loop is fully unrolled)
-template <int NS>
+// BF16P (partials of swa_prefill_kernel): part_o holds NORMALISED rows O_s / l_s in bf16 (half the round trip of the
+// split-KV partials, which is 17 MB per launch in fp32 at the bench shape); the merge weights are then w_s l_s.
+template <int NS, bool BF16P>
 __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                          bf16_t* __restrict__ o, int B, int rows_per_b, int nsplit, AppendArgs ap) {
   if (ap.first_block >= 0 && (int)blockIdx.x >= ap.first_block) {
@@ -1239,7 +1234,12 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
       const float2 ml = *(const float2*)(part_ml + pr * 2);
       ms[s] = on ? ml.x : -INFINITY;
       ls[s] = on ? ml.y : 0.f;
-      ov[s] = *(const float2*)(part_o + pr * SWA_D + 2 * lane);
+      if (BF16P) {
+        const unsigned int w2 = *(const unsigned int*)((const bf16_t*)part_o + pr * SWA_D + 2 * lane);
+        ov[s] = float2{bflo(w2), bfhi(w2)};
+      } else {
+        ov[s] = *(const float2*)(part_o + pr * SWA_D + 2 * lane);
+      }
     }
     float m = -INFINITY;
 #pragma unroll
@@ -1247,8 +1247,9 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
     float l = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float w = ms[s] == -INFINITY ? 0.f : exp2f(ms[s] - m);
-      l = fmaf(w, ls[s], l);
+      float w = ms[s] == -INFINITY ? 0.f : exp2f(ms[s] - m);
+      if (BF16P) w *= ls[s];
+      l = BF16P ? l + w : fmaf(w, ls[s], l);
       a0 = fmaf(w, ov[s].x, a0);
       a1 = fmaf(w, ov[s].y, a1);
     }
@@ -1427,9 +1428,12 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     if (append_blocks > 0) ap.first_block = (int)gb;
     const dim3 cg((int)gb + append_blocks);
     if (nsplit > 16) hipLaunchKernelGGL(swa_combine_wide_kernel, cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
-    else if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
-    else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
-    else hipLaunchKernelGGL((swa_combine_kernel<16>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (prefill && nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (prefill && nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (prefill) hipLaunchKernelGGL((swa_combine_kernel<16, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4, false>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else if (nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8, false>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    else hipLaunchKernelGGL((swa_combine_kernel<16, false>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
     rc = check_launch("ivl_swa_fwd(combine)");
   } else if (append_blocks > 0) {
     ap.first_block = 0;
