@@ -1293,3 +1293,29 @@ def test_rope_tables_kernel_matches_the_eager_chain():
     x = torch.zeros(1, dtype=torch.bfloat16, device=DEV)
     c2, s2 = rot(x, pos)
     assert torch.equal(c2, cos) and torch.equal(s2, sin)
+
+
+@pytest.mark.parametrize("B,T,seen,W,rope", [(1, 256, 4500, 4096, True), (1, 256, 9000, 4096, False), (2, 1, 300, 96, True),
+                                             (1, 4096, 100, 1024, False), (1, 70, 40, 96, True), (1, 5000, 0, 4096, False)])
+def test_swa_append_folded_into_the_call_equals_separate_append(B, T, seen, W, rope):
+    """ivl_swa_args.append_new (the ring append riding in the split-KV combine launch, or launched by ivl_swa_fwd itself when
+    there is no combine) must leave the ring exactly as ivl_swa_cache_append does (reference tail copy-back, std:146-172):
+    split and unsplit prefill, decode, T > capacity, with and without the fused rotation of the keys."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d, C = 16, 2, 128, W - 1
+    g_ = torch.Generator(device=DEV).manual_seed(T + seen)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    q, k, v = rn(B, T, Hq, d), rn(B, T, Hkv, d), rn(B, T, Hkv, d)
+    kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
+    pos_dev = torch.full((1,), seen, dtype=torch.int64, device=DEV)
+    rp = None
+    if rope:
+        cos, sin = rn(3, B, T, d), rn(3, B, T, d)
+        rp = (cos, sin, [16, 24, 24])
+    kc1, vc1, kc2, vc2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    o1 = ops.swa_forward(q, k, v, window=W, scaling=d ** -0.5, k_cache=kc1, v_cache=vc1, pos_dev=pos_dev, rope=rp)
+    ops.swa_cache_append(k, v, kc1, vc1, pos_dev=pos_dev, rope=rp)
+    o2 = ops.swa_forward(q, k, v, window=W, scaling=d ** -0.5, k_cache=kc2, v_cache=vc2, pos_dev=pos_dev, rope=rp, append=True)
+    assert torch.equal(o1, o2)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    assert not torch.equal(kc, kc2)
