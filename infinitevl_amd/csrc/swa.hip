@@ -1267,14 +1267,21 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
     ring_append(ap, (long long)blockIdx.x - ap.first_block, (long long)gridDim.x - ap.first_block);
     return;
   }
+  // one WORKGROUP per row: wave w merges the splits 16w .. 16w + 15 (all 16 partial rows requested at once: one memory
+  // round trip instead of nsplit / 8), the four partial sums meet in LDS
+  __shared__ float2 red[4][64];
   const int ncb = ap.first_block >= 0 ? ap.first_block : (int)gridDim.x;       // combine blocks
-  const int lane = threadIdx.x & 63;
-  const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)ncb * blockDim.x) >> 6;
-  for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long r = blockIdx.x; r < (long long)B * rows_per_b; r += ncb) {
     const long long b = r / rows_per_b, rr = r % rows_per_b;
     const bool on = lane < nsplit;
     const float2 ml = *(const float2*)(part_ml + ((b * nsplit + (on ? lane : 0)) * rows_per_b + rr) * 2);
+    float2 ov[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int s2 = min(16 * wave + j, nsplit - 1);
+      ov[j] = *(const float2*)(part_o + ((b * nsplit + s2) * rows_per_b + rr) * SWA_D + 2 * lane);
+    }
     const float ms = on ? ml.x : -INFINITY;
     float m = ms;
 #pragma unroll
@@ -1282,22 +1289,21 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
     const float w = ms == -INFINITY ? 0.f : exp2f(ms - m);
     const float l = wave_sum(w * (on ? ml.y : 0.f));
     float a0 = 0.f, a1 = 0.f;
-    for (int s0 = 0; s0 < nsplit; s0 += 8) {
-      float2 ov[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int s2 = min(s0 + j, nsplit - 1);
-        ov[j] = *(const float2*)(part_o + ((b * nsplit + s2) * rows_per_b + rr) * SWA_D + 2 * lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float ws = s0 + j < nsplit ? __shfl(w, s0 + j, 64) : 0.f;
-        a0 = fmaf(ws, ov[j].x, a0);
-        a1 = fmaf(ws, ov[j].y, a1);
-      }
+    for (int j = 0; j < 16; ++j) {
+      const int s2 = 16 * wave + j;
+      const float ws = s2 < nsplit ? __shfl(w, s2, 64) : 0.f;
+      a0 = fmaf(ws, ov[j].x, a0);
+      a1 = fmaf(ws, ov[j].y, a1);
     }
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    *(unsigned int*)(o + r * SWA_D + 2 * lane) = pack2bf(a0 * inv, a1 * inv);
+    red[wave][lane] = float2{a0, a1};
+    __syncthreads();
+    if (wave == 0) {
+      const float2 p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      *(unsigned int*)(o + r * SWA_D + 2 * lane) = pack2bf((a0 + p1.x + p2.x + p3.x) * inv, (a1 + p1.y + p2.y + p3.y) * inv);
+    }
+    __syncthreads();
   }
 }
 
@@ -1427,7 +1433,12 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
     if (gb > 4096) gb = 4096;
     if (append_blocks > 0) ap.first_block = (int)gb;
     const dim3 cg((int)gb + append_blocks);
-    if (nsplit > 16) hipLaunchKernelGGL(swa_combine_wide_kernel, cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
+    if (nsplit > 16) {
+      long long wb = nrows > 4096 ? 4096 : nrows;                 // one workgroup per row
+      if (append_blocks > 0) ap.first_block = (int)wb;
+      hipLaunchKernelGGL(swa_combine_wide_kernel, dim3((int)wb + append_blocks), dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B,
+                         a->T * a->Hq, nsplit, ap);
+    }
     else if (prefill && nsplit <= 4) hipLaunchKernelGGL((swa_combine_kernel<4, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
     else if (prefill && nsplit <= 8) hipLaunchKernelGGL((swa_combine_kernel<8, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
     else if (prefill) hipLaunchKernelGGL((swa_combine_kernel<16, true>), cg, dim3(256), 0, st, p.part_o, p.part_ml, p.o, a->B, a->T * a->Hq, nsplit, ap);
