@@ -36,6 +36,7 @@ struct SwaParams {
   const bf16_t* q; const bf16_t* k_new; const bf16_t* v_new; const bf16_t* k_cache; const bf16_t* v_cache;
   bf16_t* o;
   long long q_sb, q_st, q_sh, kn_sb, kn_st, kn_sh;
+  long long vn_sb, vn_st, vn_sh;           // strides of v_new (= kn_* unless the keys come from the rope pre-pass copy)
   int B, T, T_new, Hq, Hkv, C, W, nsplit, n_qtiles;
   long long pos; const long long* pos_dev;
   float scaling;
@@ -571,10 +572,11 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
     const int chunk0 = is_k ? (wave == 8 ? 0 : 9) : (wave == 10 ? 0 : 10);
     const int nch = is_k ? (wave == 8 ? 9 : 8) : 10;                      // chunks of this wave
     const long long ring_off = p.C > 0 ? (((long long)b * p.Hkv + hk) * p.C) * SWA_D : 0;
-    const long long new_off = (long long)b * p.kn_sb + (long long)hk * p.kn_sh;
+    const long long n_sb = is_k ? p.kn_sb : p.vn_sb, n_st = is_k ? p.kn_st : p.vn_st, n_sh = is_k ? p.kn_sh : p.vn_sh;
+    const long long new_off = (long long)b * n_sb + (long long)hk * n_sh;
     const bf16_t* const b_ring = p.C > 0 ? (is_k ? p.k_cache : p.v_cache) + ring_off : (is_k ? p.k_new : p.v_new);
     const bf16_t* const b_new = (is_k ? p.k_new : p.v_new) + new_off;
-    const unsigned int kn_st32 = (unsigned int)p.kn_st;
+    const unsigned int kn_st32 = (unsigned int)n_st;
     const long long rplane = (long long)p.B * p.T * SWA_D;
     const bf16_t* const rope_cos = p.rcos + (long long)b * p.T * SWA_D;
     const bf16_t* const rope_sin = p.rsin + (long long)b * p.T * SWA_D;
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       const int j0 = kt * SWA_KT, slot0 = s0 + j0;
       const unsigned long long base_u = ring_fast
           ? (unsigned long long)(b_ring + (long long)(slot0 >= p.C ? slot0 - p.C : slot0) * SWA_D)
-          : (unsigned long long)(b_new + (long long)(j0 - n_ring) * p.kn_st);
+          : (unsigned long long)(b_new + (long long)(j0 - n_ring) * n_st);
       const unsigned char* const base = (const unsigned char*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(base_u >> 32)) << 32) |
                                                                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)base_u));
       const unsigned int lds0 = (unsigned int)(size_t)smem + img0 + (unsigned int)st * img_bytes + (unsigned int)chunk0 * 1024u;
@@ -1172,11 +1174,39 @@ __global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
   }
 }
 
+// M-RoPE pre-pass of a split-KV prefill call: q and the call's keys are rotated ONCE into the workspace (contiguous
+// [B,T,H,128]) and the attention kernel runs on rotated data.  Rotating inside the attention kernel repeats the work in every
+// split and every q head of a kv group: at the step shape (8 splits) the q rope alone cost every workgroup 128 KB of
+// cos / sin traffic and ~5 us per launch; the pre-pass costs one ~2 us launch.  Same arithmetic (rope_pair): bit-identical.
+__global__ __launch_bounds__(256) void swa_rope_prepass_kernel(const bf16_t* __restrict__ q, long long q_sb, long long q_st, long long q_sh,
+                                                              const bf16_t* __restrict__ k, long long k_sb, long long k_st, long long k_sh,
+                                                              bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_out, int B, int T, int Hq,
+                                                              int Hkv, const bf16_t* __restrict__ rcos, const bf16_t* __restrict__ rsin,
+                                                              int rs0, int rs1) {
+  const int HT = Hq + Hkv;
+  const long long total = (long long)B * T * HT * 8;               // (row, head, channel-block pair c, c + 8)
+  const long long plane = (long long)B * T * SWA_D;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx & 7);
+    const int h = (int)((idx >> 3) % HT);
+    const long long bt = (idx >> 3) / HT;
+    const int b = (int)(bt / T), t = (int)(bt % T);
+    const bool is_q = h < Hq;
+    const bf16_t* src = is_q ? q + (long long)b * q_sb + (long long)t * q_st + (long long)h * q_sh
+                             : k + (long long)b * k_sb + (long long)t * k_st + (long long)(h - Hq) * k_sh;
+    u32x4 lo = *(const u32x4*)(src + 8 * c), hi = *(const u32x4*)(src + 8 * c + 64);
+    rope_pair(lo, hi, rcos, rsin, plane, bt * SWA_D, 8 * c, rs0, rs1);
+    bf16_t* dst = is_q ? q_out + (bt * Hq + h) * SWA_D : k_out + (bt * Hkv + (h - Hq)) * SWA_D;
+    *(u32x4*)(dst + 8 * c) = lo;
+    *(u32x4*)(dst + 8 * c + 64) = hi;
+  }
+}
+
 // Ring append folded into the combine launch (ivl_swa_args.append_new): the blocks behind the combine blocks copy the
 // call's tokens into the ring.  The attention kernel has finished by then (stream order), so no reader of the old
 // slots is left; one launch per layer and step instead of two.
 struct AppendArgs {
-  const bf16_t* k_new; const bf16_t* v_new; long long kn_sb, kn_st, kn_sh;
+  const bf16_t* k_new; const bf16_t* v_new; long long kn_sb, kn_st, kn_sh, vn_sb, vn_st, vn_sh;
   bf16_t* k_cache; bf16_t* v_cache;
   int B, T, Hkv, C; long long pos; const long long* pos_dev;
   const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
@@ -1204,7 +1234,8 @@ __device__ __forceinline__ void ring_append(const AppendArgs& a, long long block
       kv = ch < 8 ? lo : hi;
     }
     *(u32x4*)(a.k_cache + dst) = kv;
-    *(u32x4*)(a.v_cache + dst) = *(const u32x4*)(a.v_new + src);
+    *(u32x4*)(a.v_cache + dst) =
+        *(const u32x4*)(a.v_new + ((long long)b * a.vn_sb + (long long)tt * a.vn_st + (long long)hk * a.vn_sh + ch * 8));
   }
 }
 
@@ -1338,8 +1369,10 @@ extern "C" size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d) {
   if (B <= 0 || T <= 0 || Hq <= 0 || d != SWA_D) return 0;
   int ns = swa_base_nsplit(B, T, Hq);
   if (T <= SWA_QT) ns = SWA_MAX_SPLIT_PACK;      // packed decode rows may use the maximum split
+  // split-KV partials (+ the rotated q / k copies of the rope pre-pass: at most 2 Hq heads of bf16 rows)
+  const size_t rot = T > SWA_QT ? (size_t)B * T * Hq * SWA_D * 2 * sizeof(bf16_t) : 0;
   if (ns == 1) return 256;
-  return (size_t)B * ns * T * Hq * (SWA_D + 2) * sizeof(float) + 256;
+  return (size_t)B * ns * T * Hq * (SWA_D + 2) * sizeof(float) + rot + 256;
 }
 
 extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
@@ -1390,6 +1423,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   p.q = (const bf16_t*)a->q; p.k_new = (const bf16_t*)a->k_new; p.v_new = (const bf16_t*)a->v_new;
   p.k_cache = (const bf16_t*)a->k_cache; p.v_cache = (const bf16_t*)a->v_cache; p.o = (bf16_t*)a->o;
   p.q_sb = a->q_sb; p.q_st = a->q_st; p.q_sh = a->q_sh; p.kn_sb = a->kn_sb; p.kn_st = a->kn_st; p.kn_sh = a->kn_sh;
+  p.vn_sb = a->kn_sb; p.vn_st = a->kn_st; p.vn_sh = a->kn_sh;
   p.B = a->B; p.T = a->T; p.T_new = a->T_new; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity; p.W = a->window;
   p.nsplit = nsplit; p.pos = a->pos; p.pos_dev = (const long long*)a->pos_dev; p.scaling = a->scaling;
   p.part_o = nullptr; p.part_ml = nullptr;
@@ -1405,9 +1439,28 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   const int rows = pack ? a->T * G : a->T;
   const int qg = pack ? 1 : swa_qg(a->B, a->T, a->Hq);
   const bool prefill = !pack && a->T > SWA_QT;
+  hipStream_t st = (hipStream_t)stream;
+  if (prefill && nsplit > 1 && p.rcos != nullptr) {
+    // rotate q and the call's keys once, into the workspace behind the partials (see swa_rope_prepass_kernel)
+    const size_t n_part = ((size_t)a->B * nsplit * a->T * a->Hq * (SWA_D + 2)) * sizeof(float);
+    const size_t n_q = (size_t)a->B * a->T * a->Hq * SWA_D, n_k = (size_t)a->B * a->T * a->Hkv * SWA_D;
+    IVL_REQUIRE(a->workspace_bytes >= n_part + (n_q + n_k) * sizeof(bf16_t), IVL_ERR_WORKSPACE,
+                "ivl_swa_fwd: workspace %zu bytes < required %zu (rope pre-pass)", a->workspace_bytes, n_part + (n_q + n_k) * sizeof(bf16_t));
+    bf16_t* q_rot = (bf16_t*)((unsigned char*)a->workspace + n_part);
+    bf16_t* k_rot = q_rot + n_q;
+    const long long items = (long long)a->B * a->T * (a->Hq + a->Hkv) * 8;
+    long long gb = (items + 255) / 256;
+    if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(swa_rope_prepass_kernel, dim3((int)gb), dim3(256), 0, st, p.q, p.q_sb, p.q_st, p.q_sh, p.k_new, p.kn_sb, p.kn_st,
+                       p.kn_sh, q_rot, k_rot, a->B, a->T, a->Hq, a->Hkv, p.rcos, p.rsin, p.rs0, p.rs1);
+    int rc0 = check_launch("ivl_swa_fwd(rope pre-pass)");
+    if (rc0 != IVL_OK) return rc0;
+    p.q = q_rot; p.q_sb = (long long)a->T * a->Hq * SWA_D; p.q_st = (long long)a->Hq * SWA_D; p.q_sh = SWA_D;
+    p.k_new = k_rot; p.kn_sb = (long long)a->T * a->Hkv * SWA_D; p.kn_st = (long long)a->Hkv * SWA_D; p.kn_sh = SWA_D;
+    p.rcos = nullptr; p.rsin = nullptr;
+  }
   p.n_qtiles = prefill ? (rows + PF_QT - 1) / PF_QT : (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
-  hipStream_t st = (hipStream_t)stream;
   if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(PF_THREADS), 0, st, p);
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
     hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
@@ -1420,6 +1473,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   int append_blocks = 0;
   if (a->append_new) {
     ap.k_new = p.k_new; ap.v_new = p.v_new; ap.kn_sb = p.kn_sb; ap.kn_st = p.kn_st; ap.kn_sh = p.kn_sh;
+    ap.vn_sb = p.vn_sb; ap.vn_st = p.vn_st; ap.vn_sh = p.vn_sh;
     ap.k_cache = (bf16_t*)a->k_cache; ap.v_cache = (bf16_t*)a->v_cache;
     ap.B = a->B; ap.T = a->T; ap.Hkv = a->Hkv; ap.C = a->cache_capacity; ap.pos = a->pos; ap.pos_dev = p.pos_dev;
     ap.rcos = p.rcos; ap.rsin = p.rsin; ap.rs0 = p.rs0; ap.rs1 = p.rs1;
@@ -1471,6 +1525,7 @@ extern "C" int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_
   if (gb > 2048) gb = 2048;
   AppendArgs ap;
   ap.k_new = (const bf16_t*)k_new; ap.v_new = (const bf16_t*)v_new; ap.kn_sb = kn_sb; ap.kn_st = kn_st; ap.kn_sh = kn_sh;
+  ap.vn_sb = kn_sb; ap.vn_st = kn_st; ap.vn_sh = kn_sh;
   ap.k_cache = (bf16_t*)k_cache; ap.v_cache = (bf16_t*)v_cache; ap.B = B; ap.T = T; ap.Hkv = Hkv; ap.C = cache_capacity;
   ap.pos = (long long)pos; ap.pos_dev = (const long long*)pos_dev;
   ap.rcos = (const bf16_t*)rope_cos; ap.rsin = (const bf16_t*)rope_sin; ap.rs0 = rope_s0; ap.rs1 = rope_s1; ap.first_block = 0;

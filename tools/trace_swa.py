@@ -20,6 +20,8 @@ kw = {}
 if cache:
     kw = dict(k_cache=rn(B, Hkv, W, d), v_cache=rn(B, Hkv, W, d),
               pos_dev=torch.full((1,), 10 * W, dtype=torch.int64, device=dev))
+if os.environ.get("IVL_TRACE_ROPE"):           # fused M-RoPE (un-rotated q / k + tables)
+    kw["rope"] = (rn(3, B, T, d), rn(3, B, T, d), [16, 24, 24])
 run = lambda: ops.swa_forward(q, kn, vn, window=W, scaling=d ** -0.5, **kw)
 trace = torch.zeros(64, dtype=torch.int64, device=dev)
 lib.ivl_debug_set_trace.argtypes = [ctypes.c_void_p]
@@ -41,7 +43,8 @@ for it in range(3):
     t = trace.cpu().tolist()
     n = max(t[40], 1)
     if t[42]:      # the 128-row prefill kernel (wave 0 = key half 0, wave 4 = key half 1)
-        print(f"--- iter {it} (prefill kernel): tiles {t[40]} | prologue {t[32]} | tile loop {t[47]} = {t[47]//n} per tile | epilogue {t[38]} | total {t[39]}")
+        print(f"--- iter {it} (prefill kernel): tiles {t[40]} | prologue {t[32]} | tile loop {t[47]} = {t[47]//n} per tile | epilogue {t[38]} | total {t[39]} "
+              f"| prologue parts: setup {t[28]}, q + rope loads issued {t[26]}, rope math {t[27]}")
         print(f"      key half 0 per tile: A (QK + row max) {t[33]//n} + wait {t[34]//n} | B (exps + PV) {t[35]//n} + wait {t[36]//n}")
         print(f"      key half 1 per tile: A (QK + row max) {t[50]//n} + wait {t[51]//n} | B (exps + PV) {t[52]//n} + wait {t[53]//n}")
         print(f"      loader wave 8 (K) per tile: issue DMA {t[55]//n} + wait {t[56]//n} | vmcnt {t[59]//n} + wait {t[60]//n}")
