@@ -225,6 +225,17 @@ def kernel_timings(device, chunk, window, only=None):
     qsL, knL, vnL = rn(B, TL, Hq, d), rn(B, TL, Hkv, d), rn(B, TL, Hkv, d)
     add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),
         5, 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
+    # vision tower (not part of the text-stack step): 8 frames of 32 x 32 patches, 16 heads x 80,
+    # rotary embedding folded in; a window layer (64-patch segments) and a full-attention layer (one segment per frame).
+    # flops = 4 * d * H * sum(len^2) (non-causal)
+    Hv, dv, frames, per = 16, 80, 8, 1024
+    qkv = rn(frames * per, 3, Hv, dv)
+    vcos, vsin = (torch.randn(frames * per, dv, device=device, generator=g_) for _ in range(2))
+    for tag, seg in (("window layer, 64-patch segments", 64), ("full layer, 1024-patch segments", 1024)):
+        cu = torch.arange(0, frames * per + 1, seg, dtype=torch.int32, device=device)
+        add(f"vision_attn({tag})@8 frames", lambda cu=cu, seg=seg: ops.vision_window_attention(
+            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg, rope=(vcos, vsin)), 20, 0, "mfma",
+            4.0 * dv * Hv * (frames * per // seg) * seg * seg)
     return res
 
 

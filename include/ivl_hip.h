@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 3
+#define IVL_ABI_VERSION 4
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -204,6 +204,30 @@ IVL_API int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t k
  * `advance` is reserved (pass 0). */
 IVL_API int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int rows,
                         int half_dim, float attention_scaling, int64_t advance, void* stream);
+
+/* Vision-tower window attention: NON-causal softmax attention inside each segment
+ * [cu_seqlens[s], cu_seqlens[s+1]) of one packed patch sequence, with the vision rotary embedding folded into the Q / K
+ * loads.  Replaces apply_rotary_pos_emb_vision (strm:657-671) + the per-window attention_interface loop / the
+ * flash-attention varlen call of InfiniteVLVisionAttention.forward (strm:752-796 = std:623-664).
+ *   q, k, v : bf16, token t / head h at element offset t * x_st + h * x_sh (the three slices of the fused qkv projection
+ *             output [S, 3, H, d] are passed without a copy); o : bf16 with its own strides ([S, H, d] contiguous for proj)
+ *   cu_seqlens : device int32 [n_seg + 1], ascending, cu_seqlens[0] = 0 (strm:1076-1077); never read on the host
+ *   max_seqlen : an upper bound of the segment lengths (the grid is sized from it; longer segments are NOT processed)
+ *   d          : head_dim, 64 / 80 / 128 built (80 = the 3B vision tower: 1280 / 16)
+ *   rope_cos, rope_sin : fp32 [S, d] (emb.cos(), emb.sin() of strm:1073-1074) or both NULL when q, k are already
+ *             rotated; the rotation is done in fp32 with separately rounded products and sum, rounded to bf16 once:
+ *             bit-identical to the reference's eager arithmetic.
+ *   S          : number of tokens (patches) in the packed sequence
+ *   workspace  : ivl_vision_attn_workspace_bytes(S, H, d, max_seqlen) bytes (0 when max_seqlen <= 64) or NULL.  With rope
+ *             tables and segments longer than one 64-row query tile, q and k are rotated ONCE into it by a pre-pass;
+ *             without it the rotation is redone in every query tile's loads (same results, slower).
+ * Scores and the softmax statistics are fp32, the probabilities are rounded to bf16 for the PV product, fp32 accumulation. */
+IVL_API size_t ivl_vision_attn_workspace_bytes(int S, int H, int d, int max_seqlen);
+IVL_API int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                        int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh,
+                        int64_t o_st, int64_t o_sh, const int32_t* cu_seqlens, int n_seg, int max_seqlen,
+                        int S, int H, int d, float scaling, const float* rope_cos, const float* rope_sin,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* *counter += delta on the device (graph-replayable position bookkeeping). */
 IVL_API int ivl_counter_add(int64_t* counter, int64_t delta, void* stream);

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "ivl_gdn_prologue_fwd", "ivl_rmsnorm_swish_gate_strided_fwd", "ivl_mrope_strided_fwd",
     "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd", "ivl_linear_small_m_fwd",
     "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd", "ivl_rope_tables_fwd",
+    "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd",
 )
 
 
@@ -82,6 +83,10 @@ def load(path: str = None) -> ctypes.CDLL:
                                             [i, i, i, i, i, i, f, i, vp, sz, vp])
     lib.ivl_rope_tables_fwd.restype = i
     lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, c_int64, vp]
+    lib.ivl_vision_attn_workspace_bytes.restype = sz
+    lib.ivl_vision_attn_workspace_bytes.argtypes = [i, i, i, i]
+    lib.ivl_vision_attn_fwd.restype = i
+    lib.ivl_vision_attn_fwd.argtypes = [vp, vp, vp, vp] + [c_int64] * 8 + [vp, i, i, i, i, i, f, vp, vp, vp, sz, vp]
     lib.ivl_gdn_gate_fwd.restype = i
     lib.ivl_gdn_gate_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp]
     lib.ivl_short_conv_fwd.restype = i

@@ -288,11 +288,13 @@ extern "C" int ivl_abi_version(void) { return IVL_ABI_VERSION; }
 namespace ivl {
 void trace_set_gdn(void* p);
 void trace_set_swa(void* p);
+void trace_set_vis(void* p);
 extern int g_scan_ncw;
 }
 extern "C" IVL_API void ivl_debug_set_trace(void* device_buffer) {
   ivl::trace_set_gdn(device_buffer);
   ivl::trace_set_swa(device_buffer);
+  ivl::trace_set_vis(device_buffer);
 }
 extern "C" IVL_API void ivl_debug_set_scan_waves(int ncw) { ivl::g_scan_ncw = ncw; }
 #endif

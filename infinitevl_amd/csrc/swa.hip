@@ -822,13 +822,13 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       need = __any(m_new > m_run);
       alpha = __builtin_amdgcn_exp2f(m_run - m_use);     // 1 for a row whose maximum did not move, 0 for a first tile
       m_run = m_new;
-    };
-    auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
-      // rescale by the factor of the running maximum (1 for a row whose maximum did not move): unconditional - a branch
-      // around it makes the compiler keep two copies of the accumulators and move 64 registers per tile
+      // rescale by the factor of the running maximum, unconditionally (a branch around it makes the compiler keep two copies
+      // of the accumulators and move 64 registers per tile) and HERE, in segment A: B (exponentials + PV) is the longer one
 #pragma unroll
       for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
       l_run *= alpha;
+    };
+    auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
       float rsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

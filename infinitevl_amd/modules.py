@@ -347,6 +347,44 @@ class GatedDeltaNet(nn.Module):
         return o, None
 
 
+class InfiniteVLVisionAttention(nn.Module):
+    """Vision-tower attention block (strm:713-801 = std:583-668): fused `qkv` projection (bias), vision rotary embedding,
+    NON-causal attention inside each window / frame segment of `cu_seqlens`, `proj`.  Parameter names and shapes match the
+    checkpoint (`qkv` [3*dim, dim] + bias, `proj` [dim, dim] + bias).  The rotary embedding and the per-segment attention
+    run in ONE launch (ops.vision_window_attention) on the strided q / k / v slices of the qkv output - no per-window
+    Python loop, no `.tolist()` host sync (strm:775-778), so the tower is graph-capturable for any `cu_seqlens` bounded by
+    `max_seqlen`.
+
+    forward(hidden_states [S, dim], cu_seqlens int32 [n+1], rotary_pos_emb=None, position_embeddings=(cos, sin) [S, head_dim],
+    max_seqlen=None) -> [S, dim].  `max_seqlen` (kwarg; the reference computes it on the device, strm:754) is an upper bound
+    of the segment lengths; when omitted it is read from `cu_seqlens` with a host sync, like the reference's own fallback."""
+
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.dim = config.hidden_size
+        self.num_heads = config.num_heads
+        self.head_dim = self.dim // self.num_heads
+        self.num_key_value_groups = 1
+        self.qkv = nn.Linear(self.dim, self.dim * 3, bias=True)
+        self.proj = nn.Linear(self.dim, self.dim)
+        self.scaling = self.head_dim ** -0.5
+        self.config = config
+        self.attention_dropout = 0.0
+        self.is_causal = False
+
+    def forward(self, hidden_states: torch.Tensor, cu_seqlens: torch.Tensor, rotary_pos_emb: Optional[torch.Tensor] = None,
+                position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, **kwargs) -> torch.Tensor:
+        seq_length = hidden_states.shape[0]
+        qkv = self.qkv(hidden_states).view(seq_length, 3, self.num_heads, self.head_dim)
+        max_seqlen = kwargs.get("max_seqlen", None)
+        if max_seqlen is None:
+            win = kwargs.get("win_lengths_list", None)                      # the streaming variant's precomputed list (strm:773)
+            max_seqlen = max(win) if win else int((cu_seqlens[1:] - cu_seqlens[:-1]).max())
+        attn = ops.vision_window_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, int(max_seqlen), self.scaling,
+                                           rope=position_embeddings)
+        return self.proj(attn.view(seq_length, -1))
+
+
 def _conv_into(mod: "ops.ShortConvolution", x: torch.Tensor, prev: Optional[torch.Tensor], dst: torch.Tensor):
     """Run the short conv reading history from `prev` (None = zero history, the reference's first call,
     std:298-300) and writing the new state into the pre-allocated cache tensor `dst` (may alias prev)."""

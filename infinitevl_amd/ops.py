@@ -230,6 +230,37 @@ def rope_tables(position_ids: torch.Tensor, inv_freq: torch.Tensor, attention_sc
     return cos, sin
 
 
+def vision_window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
+                            scaling: Optional[float] = None, rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """Non-causal attention inside each segment [cu_seqlens[s], cu_seqlens[s+1]) of a packed patch sequence: the
+    per-window attention_interface loop / flash-attention varlen call of InfiniteVLVisionAttention.forward
+    (strm:752-796), with apply_rotary_pos_emb_vision (strm:657-671) folded in when `rope=(cos, sin)` ([S, d] fp32) is given.
+
+    q, k, v: [S, H, d] bf16, any token / head strides with a contiguous channel dimension (the slices of the fused qkv
+    projection are taken as they are).  cu_seqlens: int32 [n_seg + 1] on the device, never read on the host;
+    `max_seqlen` bounds the segment lengths.  Returns [S, H, d] bf16 contiguous (what `proj` consumes after a reshape)."""
+    _need_gpu(q, k, v, cu_seqlens)
+    S, H, d = q.shape
+    assert k.shape == q.shape and v.shape == q.shape, "q, k, v must share [S, H, d]"
+    assert q.dtype == k.dtype == v.dtype == torch.bfloat16, "bf16 activations"
+    fix = lambda x: x if x.stride(-1) == 1 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and x.data_ptr() % 16 == 0 else x.contiguous()
+    q, k, v = fix(q), fix(k), fix(v)
+    cu = cu_seqlens if cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous() else cu_seqlens.to(torch.int32).contiguous()
+    cos = sin = None
+    if rope is not None:
+        cos, sin = (x if x.dtype == torch.float32 and x.is_contiguous() else x.float().contiguous() for x in rope)
+        assert tuple(cos.shape) == (S, d) and tuple(sin.shape) == (S, d), "vision rotary tables are [S, head_dim]"
+    o = torch.empty(S, H, d, dtype=torch.bfloat16, device=q.device)
+    lib = _lib.load()
+    ws_bytes = lib.ivl_vision_attn_workspace_bytes(S, H, d, int(max_seqlen)) if cos is not None else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
+    _lib.check(lib.ivl_vision_attn_fwd(
+        _p(q), _p(k), _p(v), _p(o), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+        o.stride(0), o.stride(1), _p(cu), cu.numel() - 1, int(max_seqlen), S, H, d,
+        float(d ** -0.5 if scaling is None else scaling), _p(cos), _p(sin), _p(ws), ws_bytes, _stream(q)))
+    return o
+
+
 def gdn_gate(a: torch.Tensor, b: torch.Tensor, A_log: torch.Tensor, dt_bias: torch.Tensor):
     """g = -exp(A_log) * softplus(a + dt_bias) (fp32), beta = sigmoid(b) (bf16); std:1293-1294.
     a, b are the a_proj / b_proj outputs [..., H] in bf16."""

@@ -541,13 +541,60 @@ def gen_stack_realdims(ns):
     save("stack_realdims", **out)
 
 
+def gen_vision(ns):
+    """Vision-tower window attention from the reference's own code: the vision rotary
+    embedding (InfiniteVLVisionRotaryEmbedding + apply_rotary_pos_emb_vision, bf16 in / bf16 out: bit-exact pin), the
+    per-window eager_attention_forward loop at head_dim 80 (the 3B tower's 1280 / 16), and the whole
+    InfiniteVLVisionAttention module (eager path) at hidden 320 = 4 heads x 80."""
+    print("[vision] InfiniteVLVisionAttention / apply_rotary_pos_emb_vision / eager_attention_forward at head_dim 80")
+    std = ns.std
+    torch.manual_seed(21)
+    S, H, d = 136, 8, 80
+    rot = std.InfiniteVLVisionRotaryEmbedding(d // 2)
+    pos_hw = torch.randint(0, 32, (S, 2))
+    rotary = rot(32)[pos_hw].flatten(1)                                   # what rot_pos_emb returns per patch
+    emb = torch.cat((rotary, rotary), dim=-1)
+    cos, sin = emb.cos(), emb.sin()
+    out = {"pos_hw": pos_hw.numpy(), "cos": cos, "sin": sin}
+    q, k, v = (torch.randn(S, H, d).to(torch.bfloat16) for _ in range(3))
+    qr, kr = std.apply_rotary_pos_emb_vision(q, k, cos, sin)              # bf16 -> bf16
+    out.update(q_bf16bits=bits(q), k_bf16bits=bits(k), v_bf16bits=bits(v), q_rot_bf16bits=bits(qr), k_rot_bf16bits=bits(kr))
+
+    class _M:
+        num_key_value_groups = 1
+        training = False
+    for name, cu in (("windows", [0, 64, 104, 136]), ("full", [0, 136]), ("ragged", [0, 1, 70, 70, 136])):
+        qs, ks, vs = (x.float().transpose(0, 1).unsqueeze(0) for x in (qr, kr, v))      # [1, H, S, d] as in strm:745-747
+        outs = [std.eager_attention_forward(_M(), qs[:, :, a:b], ks[:, :, a:b], vs[:, :, a:b], None, scaling=d ** -0.5)[0]
+                for a, b in zip(cu[:-1], cu[1:]) if b > a]
+        out[f"{name}_cu"] = np.asarray(cu, dtype=np.int32)
+        out[f"{name}_out"] = torch.cat(outs, dim=1)[0]                   # [S, H, d] fp32
+
+    # the module: hidden 320 = 4 heads x 80, eager path (the per-window loop of std:641-664)
+    cfg = std.InfiniteVLVisionConfig(hidden_size=320, num_heads=4, depth=1, intermediate_size=64, out_hidden_size=64)
+    cfg._attn_implementation = "eager"
+    mod = std.InfiniteVLVisionAttention(cfg).eval()
+    with torch.no_grad():
+        for prm in mod.parameters():
+            prm.copy_(snap(prm * 2.0))
+    x = snap(torch.randn(S, 320))
+    for kname, prm in mod.state_dict().items():
+        out["mod_" + kname.replace(".", "_") + "_bf16bits"] = bits(prm)
+    out["mod_x_bf16bits"] = bits(x)
+    with torch.no_grad():
+        for name, cu in (("windows", [0, 64, 104, 136]), ("full", [0, 136])):
+            out[f"mod_{name}_out"] = mod(x, torch.tensor(cu, dtype=torch.int32), position_embeddings=(cos, sin))
+    save("vision_attention", **out)
+
+
 def main():
     t0 = time.time()
     ns = load_reference_fla()
     ns = load_reference_std(ns)
     only = set(sys.argv[1:])
     steps = [("gdn", gen_gdn_ops), ("conv", gen_conv_norm), ("swa", gen_swa), ("cache", gen_cache_traces),
-             ("layers", gen_layers), ("swa_d128", gen_swa_d128), ("stack_realdims", gen_stack_realdims)]
+             ("layers", gen_layers), ("swa_d128", gen_swa_d128), ("stack_realdims", gen_stack_realdims),
+             ("vision", gen_vision)]
     for name, fn in steps:
         if only and name not in only:
             continue

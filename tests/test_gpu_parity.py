@@ -340,6 +340,93 @@ def test_swa_reference_vectors_d128():
         assert e < 5e-3, (name, e)
 
 
+# ---------------------------------------------------------------------------------------------
+# vision-tower window attention
+# ---------------------------------------------------------------------------------------------
+def test_vision_attention_reference_vectors():
+    """Pinned DIRECTLY to the reference (eager_attention_forward per window on the outputs of apply_rotary_pos_emb_vision,
+    head_dim 80): windows, one full segment, ragged (an empty and a one-patch segment).  The rotary embedding folded into
+    the kernel's loads must be BIT-identical to the reference's bf16 results: the fused call equals the call on the
+    reference's own rotated q / k, bit for bit."""
+    from infinitevl_amd import ops
+    z = load_golden("vision_attention")
+    q, k, v, qr, kr = (bf(z[n]).to(DEV) for n in ("q", "k", "v", "q_rot", "k_rot"))
+    cos, sin = z["cos"].to(DEV), z["sin"].to(DEV)
+    for name, max_len in (("windows", 64), ("full", 136), ("ragged", 69), ("ragged", 200)):
+        cu = z[name + "_cu"].to(DEV)
+        fused = ops.vision_window_attention(q, k, v, cu, max_len, rope=(cos, sin))
+        plain = ops.vision_window_attention(qr, kr, v, cu, max_len)
+        assert torch.equal(fused, plain), name
+        e = rms_rel(z[name + "_out"], fused.float().cpu())
+        assert e < 5e-3, (name, e)
+
+
+@pytest.mark.parametrize("d,H", [(80, 16), (64, 4), (128, 2)])
+def test_vision_attention_real_shapes_vs_oracle(d, H):
+    """The 3B tower's shapes (16 heads x 80): a window layer (one 32 x 32-patch frame = 16 windows of 64 patches, plus edge
+    windows of a 30 x 30 frame: 36 / 24 / 16 patches) and a full-attention layer (one segment per frame, 1024 and 900
+    patches), q / k / v taken as strided slices of one [S, 3, H, d] projection output.  Oracle with the probabilities
+    rounded to bf16 before P @ V (the kernel's rounding point): <= 5e-4... the output itself is rounded to bf16."""
+    from oracle import vision
+    from infinitevl_amd import ops
+    torch.manual_seed(5)
+    win = [64] * 16 + [64] * 9 + [48] * 6 + [36]                   # 1024 + 900 patches
+    for lens in (win, [1024, 900]):
+        S = sum(lens)
+        cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+        qkv = bf(torch.randn(S, 3, H, d))
+        pos_hw = torch.randint(0, 32, (S, 2))
+        cos, sin = vision.vision_rotary_tables(pos_hw, d)
+        got = ops.vision_window_attention(qkv.to(DEV)[:, 0], qkv.to(DEV)[:, 1], qkv.to(DEV)[:, 2], cu.to(DEV), max(lens),
+                                          rope=(cos.to(DEV), sin.to(DEV)))
+        qr, kr = vision.apply_rotary_pos_emb_vision(qkv[:, 0], qkv[:, 1], cos, sin)
+        ref = vision.segment_attention(qr, kr, qkv[:, 2], cu.tolist(), p_round_dtype=torch.bfloat16)
+        exact = vision.segment_attention(qr, kr, qkv[:, 2], cu.tolist())
+        assert rms_rel(ref, got.float().cpu()) < 3e-3 and rms_rel(exact, got.float().cpu()) < 5e-3, (d, len(lens))
+
+
+def test_vision_attention_module_matches_reference():
+    """InfiniteVLVisionAttention (same parameter names as the checkpoint) against the reference module's eager output,
+    hidden 320 = 4 heads x 80; the projections are bf16 GEMMs here (fp32 in the fixture)."""
+    from types import SimpleNamespace
+    from infinitevl_amd.modules import InfiniteVLVisionAttention
+    z = load_golden("vision_attention")
+    mod = InfiniteVLVisionAttention(SimpleNamespace(hidden_size=320, num_heads=4)).to(DEV, torch.bfloat16)
+    mod.load_state_dict({"qkv.weight": bf(z["mod_qkv_weight"]), "qkv.bias": bf(z["mod_qkv_bias"]),
+                         "proj.weight": bf(z["mod_proj_weight"]), "proj.bias": bf(z["mod_proj_bias"])})
+    x = bf(z["mod_x"]).to(DEV)
+    pe = (z["cos"].to(DEV), z["sin"].to(DEV))
+    with torch.no_grad():
+        for name in ("windows", "full"):
+            cu = z[name + "_cu"].to(DEV)
+            out = mod(x, cu, position_embeddings=pe)                               # max_seqlen read from cu_seqlens
+            out2 = mod(x, cu, position_embeddings=pe, max_seqlen=136)              # the graph-capturable form
+            assert torch.equal(out, out2)
+            e = rms_rel(z[f"mod_{name}_out"], out.float().cpu())
+            assert e < 1e-2, (name, e)
+
+
+def test_vision_attention_is_graph_capturable_and_rejects_bad_arguments():
+    from infinitevl_amd import ops
+    torch.manual_seed(6)
+    S, H, d = 200, 16, 80
+    q, k, v = (bf(torch.randn(S, H, d)).to(DEV) for _ in range(3))
+    cu = torch.tensor([0, 64, 128, 200], dtype=torch.int32, device=DEV)
+    eager = ops.vision_window_attention(q, k, v, cu, 72)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.vision_window_attention(q, k, v, cu, 72)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            o = ops.vision_window_attention(q, k, v, cu, 72)
+    cu.copy_(torch.tensor([0, 70, 130, 200], dtype=torch.int32))       # new segmentation, same graph (lengths within max_seqlen)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o, ops.vision_window_attention(q, k, v, cu, 72)) and not torch.equal(o, eager)
+    with pytest.raises(ValueError):                                       # head_dim not built: IVL_ERR_UNSUPPORTED
+        ops.vision_window_attention(q[..., :48].contiguous(), k[..., :48].contiguous(), v[..., :48].contiguous(), cu, 72)
+
+
 def _band_counts(n_prev, T, W):
     """Decode WHICH keys each row attended: q = 0 makes the softmax uniform over the visible set, V holds
     one-hot residues of the key index, so out[i, r] * n_vis(i) = #visible keys with residue r.  Two encodings: j % 128

@@ -115,6 +115,26 @@ def test_swa_attention_d128_matches_reference():
         assert rms_rel(z[name + "_out"], out) < 2e-6, name
 
 
+def test_vision_attention_matches_reference():
+    """the vision rotary embedding (bf16 in / bf16 out: BIT-exact against the reference's
+    apply_rotary_pos_emb_vision), the rotary tables from (h, w) patch coordinates, the per-window attention at head_dim 80
+    (windows / one full segment / ragged with an empty and a one-patch segment) and the whole attention block."""
+    from oracle import vision
+    z = load_golden("vision_attention")
+    cos, sin = vision.vision_rotary_tables(z["pos_hw"], 80)
+    assert torch.equal(cos, z["cos"]) and torch.equal(sin, z["sin"])
+    q, k, v = (z[n].to(torch.bfloat16) for n in ("q", "k", "v"))
+    qr, kr = vision.apply_rotary_pos_emb_vision(q, k, z["cos"], z["sin"])
+    assert torch.equal(qr.float(), z["q_rot"]) and torch.equal(kr.float(), z["k_rot"])
+    for name in ("windows", "full", "ragged"):
+        out = vision.segment_attention(z["q_rot"], z["k_rot"], z["v"], z[name + "_cu"].tolist())
+        assert rms_rel(z[name + "_out"], out) < 2e-6, name
+    for name in ("windows", "full"):
+        out = vision.vision_attention_block(z["mod_x"], z["mod_qkv_weight"], z["mod_qkv_bias"], z["mod_proj_weight"],
+                                            z["mod_proj_bias"], z[name + "_cu"].tolist(), z["cos"], z["sin"], 4)
+        assert rms_rel(z[f"mod_{name}_out"], out) < 2e-6, name
+
+
 def test_mrope_matches_reference():
     z = load_golden("mrope")
     cos, sin = swa.rotary_cos_sin(z["position_ids"], 128, float(z["theta"]))
