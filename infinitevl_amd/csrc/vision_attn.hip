@@ -70,7 +70,10 @@ __device__ __forceinline__ float va_group_sum(float x) {
 // `own` = the piece, `part` = the piece D/2 channels away, cos / sin = fp32 rows of the token at c0.  Each product and the
 // sum are rounded separately (no fused multiply-add): the reference does q.float() * cos, rotate_half(q) * sin and the
 // addition as three fp32 tensor operations and rounds the result to bf16 once (strm:665-670) - bit-identical.
+// (the contraction into v_fma is switched off per function: `__fmul_rn` / `__fadd_rn` are plain operators in the HIP headers
+// and contract like any other once inlined)
 __device__ __forceinline__ u32x4 vision_rope_piece(u32x4 own, u32x4 part, const float* cosp, const float* sinp, bool lower_half) {
+#pragma clang fp contract(off)
   const f32x4 c0 = *(const f32x4*)cosp, c1 = *(const f32x4*)(cosp + 4);
   const f32x4 s0 = *(const f32x4*)sinp, s1 = *(const f32x4*)(sinp + 4);
   const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -81,8 +84,7 @@ __device__ __forceinline__ u32x4 vision_rope_piece(u32x4 own, u32x4 part, const 
   for (int i = 0; i < 4; ++i) {
     const float a0 = bflo(xo[i]), a1 = bfhi(xo[i]);
     const float r0 = lower_half ? -bflo(xp[i]) : bflo(xp[i]), r1 = lower_half ? -bfhi(xp[i]) : bfhi(xp[i]);
-    out[i] = pack2bf(__fadd_rn(__fmul_rn(a0, cs[2 * i]), __fmul_rn(r0, sn[2 * i])),
-                     __fadd_rn(__fmul_rn(a1, cs[2 * i + 1]), __fmul_rn(r1, sn[2 * i + 1])));
+    out[i] = pack2bf(a0 * cs[2 * i] + r0 * sn[2 * i], a1 * cs[2 * i + 1] + r1 * sn[2 * i + 1]);
   }
   return u32x4{out[0], out[1], out[2], out[3]};
 }
@@ -94,8 +96,12 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   constexpr int DK = (D + 31) / 32 * 32;       // contraction length of the QK product (zero padded)
   constexpr int NKS = DK / 32;                 // QK MFMA steps
   constexpr int NDT = D / 16;                  // PV output column tiles
-  constexpr int KS = DK * 2 + 16;              // bytes per K row in LDS (padded)
-  constexpr int VS = D * 2 + 16;               // bytes per V row in LDS (padded)
+  // K rows of 256 B with the 16-byte pieces XOR-swizzled by the row (piece' = piece ^ (row & 15), as in swa.hip: the
+  // ds_read_b128 lane groups {0-3,12-15,20-27}, ... see distinct banks; a padded 208-byte row measured 37 % of the LDS
+  // cycles as bank conflicts).  V rows: ds_read_b64_tr_b16 serves 8 rows x 32 B per 32-lane group, conflict-free when the
+  // row stride is an odd multiple of 32 B: 160 B (D = 80) as it is, 128 / 256 B rows get 32 B of padding.
+  constexpr int KS = 256;
+  constexpr int VS = (D * 2 / 32) % 2 == 1 ? D * 2 : D * 2 + 32;
   constexpr int LDS_K = VA_KT * KS;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_K + VA_KT * VS];
 
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   if constexpr (DK > D) {
     constexpr int NPAD = DK / 8 - NCH;
     for (int i = tid; i < VA_KT * NPAD; i += 256)
-      *(u32x4*)(smem + (i / NPAD) * KS + (NCH + i % NPAD) * 16) = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(smem + (i / NPAD) * KS + (((NCH + i % NPAD) ^ ((i / NPAD) & 15)) << 4)) = u32x4{0u, 0u, 0u, 0u};
   }
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = srow + 16 * i;
-      *(u32x4*)(smem + r * KS + schunk * 16) = kreg[i];
+      *(u32x4*)(smem + r * KS + ((schunk ^ (r & 15)) << 4)) = kreg[i];
       *(u32x4*)(smem + LDS_K + r * VS + schunk * 16) = vreg[i];
     }
   };
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const u32x4 kf = *(const u32x4*)(smem + (16 * mt + l15) * KS + (4 * ks + g) * 16);
+        const u32x4 kf = *(const u32x4*)(smem + (16 * mt + l15) * KS + (((4 * ks + g) ^ l15) << 4));
         sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_mfma(kf), va_mfma(qf[ks]), sacc[mt], 0, 0, 0);
       }
     if (kt + 1 < n_kt) load_tile(kt + 1);      // lands under the softmax and the PV product
@@ -302,25 +308,55 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
     *(u32x2*)(op + 16 * mt2) = u32x2{pack2bf(oacc[mt2][0] * inv, oacc[mt2][1] * inv), pack2bf(oacc[mt2][2] * inv, oacc[mt2][3] * inv)};
 }
 
-// Rotary pre-pass for calls whose segments span several 64-row query tiles (the full-attention layers): every key would
-// otherwise be rotated once per query tile of its segment, and the rotation (partner piece + 64 bytes of tables per piece)
-// sits between a tile's loads and its LDS store.  One thread per 16-byte piece of q and of k -> [2][S][H][D] bf16.
+// Rotary pre-pass for calls whose segments span several 64-row query tiles (the full-attention layers): every key would otherwise be rotated once per query tile of its segment, and the rotation (partner piece + 64
+// bytes of tables per piece) sits between a tile's loads and its LDS store.  One thread per (q | k, token, group of 4 heads,
+// pair of 16-byte pieces D/2 channels apart): the 4 x 32 bytes of tables are loaded once and serve 4 heads x both pieces of
+// the pair (each piece is the other's rotate_half partner)  ->  [2][S][H][D] bf16.
 template <int D>
 __global__ __launch_bounds__(256) void vision_rope_prepass_kernel(VisionAttnParams p, bf16_t* __restrict__ out, int S, int H) {
-  constexpr int NCH = D / 8;
+#pragma clang fp contract(off)
+  constexpr int NP = D / 16;                   // piece pairs per row
+  const int hg = (H + 3) / 4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long n = (long long)S * H * NCH;
+  const long long n = (long long)S * hg * NP;
   if (idx >= 2 * n) return;
   const int which = idx >= n;
   const long long r = which ? idx - n : idx;
-  const int ch = (int)(r % NCH);
-  const int h = (int)((r / NCH) % H);
-  const long long tok = r / ((long long)NCH * H);
-  const bf16_t* src = which ? p.k + tok * p.k_st + (long long)h * p.k_sh : p.q + tok * p.q_st + (long long)h * p.q_sh;
-  const int pch = ch < NCH / 2 ? ch + NCH / 2 : ch - NCH / 2;
-  const u32x4 own = *(const u32x4*)(src + ch * 8), part = *(const u32x4*)(src + pch * 8);
-  *(u32x4*)(out + ((which * (long long)S + tok) * H + h) * D + ch * 8) =
-      vision_rope_piece(own, part, p.rcos + tok * D + ch * 8, p.rsin + tok * D + ch * 8, ch < NCH / 2);
+  const int pr = (int)(r % NP);
+  const int h0 = (int)((r / NP) % hg) * 4;
+  const long long tok = r / ((long long)NP * hg);
+  const float* cl = p.rcos + tok * D + pr * 8;
+  const float* sl = p.rsin + tok * D + pr * 8;
+  const f32x4 cl0 = *(const f32x4*)cl, cl1 = *(const f32x4*)(cl + 4), ch0 = *(const f32x4*)(cl + D / 2), ch1 = *(const f32x4*)(cl + D / 2 + 4);
+  const f32x4 sl0 = *(const f32x4*)sl, sl1 = *(const f32x4*)(sl + 4), sh0 = *(const f32x4*)(sl + D / 2), sh1 = *(const f32x4*)(sl + D / 2 + 4);
+  const float c_lo[8] = {cl0[0], cl0[1], cl0[2], cl0[3], cl1[0], cl1[1], cl1[2], cl1[3]};
+  const float c_hi[8] = {ch0[0], ch0[1], ch0[2], ch0[3], ch1[0], ch1[1], ch1[2], ch1[3]};
+  const float s_lo[8] = {sl0[0], sl0[1], sl0[2], sl0[3], sl1[0], sl1[1], sl1[2], sl1[3]};
+  const float s_hi[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+  const bf16_t* src = (which ? p.k + tok * p.k_st : p.q + tok * p.q_st) + pr * 8;
+  const long long sh = which ? p.k_sh : p.q_sh;
+  bf16_t* dst = out + ((which * (long long)S + tok) * H) * D + pr * 8;
+  u32x4 lo[4], hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int h = min(h0 + i, H - 1);
+    lo[i] = *(const u32x4*)(src + h * sh);
+    hi[i] = *(const u32x4*)(src + h * sh + D / 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (h0 + i >= H) break;
+    const unsigned int xl[4] = {lo[i].x, lo[i].y, lo[i].z, lo[i].w}, xh[4] = {hi[i].x, hi[i].y, hi[i].z, hi[i].w};
+    unsigned int ol[4], oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = bflo(xl[e]), a1 = bfhi(xl[e]), b0 = bflo(xh[e]), b1 = bfhi(xh[e]);
+      ol[e] = pack2bf(a0 * c_lo[2 * e] + (-b0) * s_lo[2 * e], a1 * c_lo[2 * e + 1] + (-b1) * s_lo[2 * e + 1]);
+      oh[e] = pack2bf(b0 * c_hi[2 * e] + a0 * s_hi[2 * e], b1 * c_hi[2 * e + 1] + a1 * s_hi[2 * e + 1]);
+    }
+    *(u32x4*)(dst + (long long)(h0 + i) * D) = u32x4{ol[0], ol[1], ol[2], ol[3]};
+    *(u32x4*)(dst + (long long)(h0 + i) * D + D / 2) = u32x4{oh[0], oh[1], oh[2], oh[3]};
+  }
 }
 
 }  // namespace ivl
@@ -328,7 +364,9 @@ __global__ __launch_bounds__(256) void vision_rope_prepass_kernel(VisionAttnPara
 using namespace ivl;
 
 extern "C" size_t ivl_vision_attn_workspace_bytes(int S, int H, int d, int max_seqlen) {
-  if (S <= 0 || H <= 0 || d <= 0 || max_seqlen <= VA_QT) return 0;      // one query tile per segment: the rotation stays fused
+  // one query tile per segment (window layers): nothing is rotated twice, the rotation stays in the tile loads (a pre-pass
+  // is a second trip of q and k through HBM: 36 vs 31 us on 8 frames of a window layer)
+  if (S <= 0 || H <= 0 || d <= 0 || max_seqlen <= VA_QT) return 0;
   return (size_t)2 * S * H * d * sizeof(bf16_t);
 }
 
@@ -357,8 +395,8 @@ extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, 
   if (rope_cos != nullptr && ws_need > 0 && workspace != nullptr && workspace_bytes >= ws_need) {
     // several query tiles per segment: rotate q and k once (without a workspace the rotation stays in the tile loads:
     // correct, but redone per query tile)
-    const long long pieces = 2ll * S * H * (d / 8);
-    const dim3 pg((unsigned int)((pieces + 255) / 256));
+    const long long work = 2ll * S * ((H + 3) / 4) * (d / 16);
+    const dim3 pg((unsigned int)((work + 255) / 256));
     bf16_t* ws = (bf16_t*)workspace;
     if (d == 80) hipLaunchKernelGGL((vision_rope_prepass_kernel<80>), pg, dim3(256), 0, st, p, ws, S, H);
     else if (d == 64) hipLaunchKernelGGL((vision_rope_prepass_kernel<64>), pg, dim3(256), 0, st, p, ws, S, H);
