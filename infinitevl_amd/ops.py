@@ -253,11 +253,11 @@ def vision_window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, c
     o = torch.empty(S, H, d, dtype=torch.bfloat16, device=q.device)
     lib = _lib.load()
     ws_bytes = lib.ivl_vision_attn_workspace_bytes(S, H, d, int(max_seqlen)) if cos is not None else 0
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes else None
+    ws = get_workspace(ws_bytes, q.device, "vision") if ws_bytes else None
     _lib.check(lib.ivl_vision_attn_fwd(
         _p(q), _p(k), _p(v), _p(o), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
         o.stride(0), o.stride(1), _p(cu), cu.numel() - 1, int(max_seqlen), S, H, d,
-        float(d ** -0.5 if scaling is None else scaling), _p(cos), _p(sin), _p(ws), ws_bytes, _stream(q)))
+        float(d ** -0.5 if scaling is None else scaling), _p(cos), _p(sin), _p(ws), ws.numel() if ws is not None else 0, _stream(q)))
     return o
 
 

@@ -16,6 +16,15 @@ from conftest import ROOT, load_golden
 from oracle import cache as ocache
 
 
+
+def _free_port():
+    """A TCP port that is free right now on 127.0.0.1 (a pid-derived constant collided now and then with a socket of an
+    earlier run still in TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
 @pytest.fixture(scope="session")
 def lib():
     so = os.path.join(ROOT, "infinitevl_amd", "libivl_hip.so")
@@ -387,7 +396,7 @@ def test_gloo_world2_gather_and_max():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300)
+    port = _free_port()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
@@ -458,7 +467,9 @@ def _sp_worker(rank, world, port, q):
     first, last = ivd.segment_bounds(total, rank, world, multiple=64)          # 128 + 22
     cache = _ToyCache(L, B, H)
     h, _ = ivd.sequence_parallel_prefill(_ToyStack(L), xs[:, first:last], cache, first)
-    q.put((rank, first, last, h, [c.state.clone() for c in cache.layers], [c.seen for c in cache.layers]))
+    # numpy, not tensors: a tensor travels through the queue as a shared-memory file descriptor that the RECEIVER fetches
+    # from this process - which may have exited by then (EOFError in 1 of ~12 runs)
+    q.put((rank, first, last, h.numpy(), [c.state.numpy().copy() for c in cache.layers], [c.seen for c in cache.layers]))
     torch.distributed.destroy_process_group()
 
 
@@ -466,7 +477,7 @@ def test_gloo_world2_sequence_parallel_prefill_matches_single_process():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29950 + (os.getpid() % 40)
+    port = _free_port()
     procs = [ctx.Process(target=_sp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
@@ -482,10 +493,10 @@ def test_gloo_world2_sequence_parallel_prefill_matches_single_process():
     pos = torch.arange(total)[None, None].expand(3, B, total)
     ref, _ = _ToyStack(L)(xs, pos, cache)
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 128, 128, 150)
-    got = torch.cat([res[0][3], res[1][3]], dim=1)
+    got = torch.cat([torch.from_numpy(res[0][3]), torch.from_numpy(res[1][3])], dim=1)
     assert torch.equal(got, ref)
     for s_ref, s_got in zip([c.state for c in cache.layers], res[1][4]):       # last rank ends with the full state
-        assert torch.equal(s_ref, s_got)
+        assert torch.equal(s_ref, torch.from_numpy(s_got))
     assert res[1][5] == [128] * L and res[0][5] == [0] * L
 
 

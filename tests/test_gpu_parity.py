@@ -19,6 +19,15 @@ from oracle import gdn as ogdn
 from oracle import swa as oswa
 import parity
 
+
+def _free_port():
+    """A TCP port that is free right now on 127.0.0.1 (a pid-derived constant collided now and then with a socket of an
+    earlier run still in TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -1289,7 +1298,7 @@ def test_sequence_parallel_prefill_two_ranks_bit_exact():
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29700 + (os.getpid() % 200)
+    port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "sp_check.py")],
