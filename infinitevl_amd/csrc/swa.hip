@@ -979,6 +979,14 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
     IVL_T(tr_fin);
     IVL_TOUT(32, tr_loop - tr_start); IVL_TOUT(38, tr_fin - tr_end); IVL_TOUT(39, tr_fin - tr_start); IVL_TOUT(40, kt_end - kt_begin);
     IVL_TOUT(42, 1); IVL_TOUT(47, tr_end - tr_loop);
+#ifdef IVL_TRACE
+    // spread of the workgroup durations: slot 44 = max, 45 = min of (cycles << 24 | tiles << 16 | split << 8 | q-tile)
+    if (ivl_trace_buf != nullptr && tid == 0) {
+      const long long v = ((tr_fin - tr_start) << 24) | ((long long)(kt_end - kt_begin) << 16) | ((long long)split << 8) | bx;
+      atomicMax((unsigned long long*)ivl_trace_buf + 44, (unsigned long long)v);
+      atomicMin((unsigned long long*)ivl_trace_buf + 45, (unsigned long long)v);
+    }
+#endif
     IVL_TOUT(33, tr_a); IVL_TOUT(34, tr_wa); IVL_TOUT(35, tr_b); IVL_TOUT(36, tr_wb);
     IVL_TOUT_AT(256, 50, tr_a); IVL_TOUT_AT(256, 51, tr_wa); IVL_TOUT_AT(256, 52, tr_b); IVL_TOUT_AT(256, 53, tr_wb);
     return;

@@ -38,6 +38,7 @@ print(f"T={T} W={W} cache={cache}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per c
 lib.ivl_debug_set_trace(ctypes.c_void_p(trace.data_ptr()))
 for it in range(3):
     trace.zero_()
+    trace[45] = 2 ** 62
     run()
     torch.cuda.synchronize()
     t = trace.cpu().tolist()
@@ -49,6 +50,8 @@ for it in range(3):
         print(f"      key half 1 per tile: A (QK + row max) {t[50]//n} + wait {t[51]//n} | B (exps + PV) {t[52]//n} + wait {t[53]//n}")
         print(f"      loader wave 8 (K) per tile: issue DMA {t[55]//n} + wait {t[56]//n} | vmcnt {t[59]//n} + wait {t[60]//n}")
         print(f"      loader wave 10 (V) per tile: vmcnt {t[57]//n} + wait {t[58]//n} | issue DMA {t[62]//n} + wait {t[63]//n}")
+        dec = lambda v: f"{v >> 24} cycles ({(v >> 16) & 255} tiles, split {(v >> 8) & 255}, q-tile {v & 255})"
+        print(f"      slowest workgroup: {dec(t[44])} | fastest: {dec(t[45])}")
         continue
     print(f"--- iter {it}: tiles {t[40]} | prologue {t[32]} | per tile: barrier1 {t[33]//n} store+barrier2 {t[34]//n} "
           f"QK issue+next loads {t[35]//n} softmax {t[36]//n} PV {t[37]//n} (sum {sum(t[33:38])//n}) | epilogue {t[38]} | total {t[39]} "
