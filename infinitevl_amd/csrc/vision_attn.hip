@@ -12,9 +12,9 @@
 // have (ring cache, band, GQA, split-KV), plus a head dimension that is not a multiple of 32:
 //   D = 80 : the QK contraction runs over 96 channels (the 16-byte pieces 10, 11 of every K row in LDS and of every Q
 //            fragment are zero: 3 MFMA steps instead of 2.5), the PV product over exactly 5 column tiles of 16.
-// Workgroup = 4 waves x 16 query rows of one (segment, 64-row tile, head); grid.x enumerates (segment, tile) pairs with
+// Workgroup = 4 waves x 16 query rows of one (head, segment, 64-row tile); the 1-D grid enumerates them with
 // ceil(max_seqlen / 64) tiles per segment (tiles beyond a segment's length exit at once: the host never reads
-// cu_seqlens, so the call is graph-capturable), grid.y = head.
+// cu_seqlens, so the call is graph-capturable), mapped onto the XCDs so that the tiles of one (segment, head) share an L2.
 #include "ivl_common.h"
 
 namespace ivl {
@@ -31,7 +31,7 @@ constexpr int VA_QT = 64, VA_KT = 64;
 struct VisionAttnParams {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
   long long q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh;      // element strides: token, head
-  const int* cu; int n_seg, tiles_per_seg;
+  const int* cu; int n_seg, tiles_per_seg, H;
   const float* rcos; const float* rsin;                          // [S, D] fp32 or NULL (inputs already rotated)
   float scaling;
 };
@@ -109,8 +109,16 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   IVL_TVAR(tv_b1); IVL_TVAR(tv_st); IVL_TVAR(tv_qk); IVL_TVAR(tv_sm); IVL_TVAR(tv_pv);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int seg = blockIdx.x / p.tiles_per_seg, tile = blockIdx.x % p.tiles_per_seg;
-  const int h = blockIdx.y;
+  // 1-D grid, XCD-aware: hardware block i runs on XCD i % 8; logical ids are ordered (segment, head, query tile), and XCD x
+  // takes the contiguous range [x N/8, (x+1) N/8) of them: the query tiles of one (segment, head) - which all read the same
+  // K / V - and the heads of one segment - which share its rotary tables and the cache lines of the qkv rows - meet in one
+  // L2 (tiles dealt round-robin made each of the 8 L2s fetch every K / V of a full layer; heads dealt round-robin made the
+  // window layers 1.5 x slower)
+  int lid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = lid % p.tiles_per_seg;
+  const int h = (lid / p.tiles_per_seg) % p.H;
+  const int seg = lid / (p.tiles_per_seg * p.H);
   const int seg0 = p.cu[seg];
   const int len = p.cu[seg + 1] - seg0;
   if (tile * VA_QT >= len) return;             // workgroup-uniform (before any barrier)
@@ -383,13 +391,13 @@ extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, 
               IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: strides must keep 16-byte (q, k, v) / 8-byte (o) alignment");
   IVL_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: misaligned pointer");
   const int tiles = (max_seqlen + VA_QT - 1) / VA_QT;
-  IVL_REQUIRE((long long)n_seg * tiles < (1ll << 31) && H < 65536, IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: grid too large");
+  IVL_REQUIRE((long long)n_seg * tiles * H < (1ll << 31), IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: grid too large");
   VisionAttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.q_st = q_st; p.q_sh = q_sh; p.k_st = k_st; p.k_sh = k_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
-  p.cu = cu_seqlens; p.n_seg = n_seg; p.tiles_per_seg = tiles;
+  p.cu = cu_seqlens; p.n_seg = n_seg; p.tiles_per_seg = tiles; p.H = H;
   p.rcos = rope_cos; p.rsin = rope_sin; p.scaling = scaling;
-  const dim3 grid(n_seg * tiles, H);
+  const dim3 grid(n_seg * tiles * H);
   hipStream_t st = (hipStream_t)stream;
   const size_t ws_need = ivl_vision_attn_workspace_bytes(S, H, d, max_seqlen);
   if (rope_cos != nullptr && ws_need > 0 && workspace != nullptr && workspace_bytes >= ws_need) {
