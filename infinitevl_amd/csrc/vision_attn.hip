@@ -89,9 +89,12 @@ __device__ __forceinline__ u32x4 vision_rope_piece(u32x4 own, u32x4 part, const 
   return u32x4{out[0], out[1], out[2], out[3]};
 }
 
-template <int D>
+// QG = 16-row query groups per wave: 1 -> 64 rows per workgroup; 2 -> 128 rows, every K / V^T fragment read from LDS feeds
+// two MFMAs and a staged tile serves twice the rows (chosen by the host when the 128-row grid still fills the chip).
+template <int D, int QG>
 __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p) {
   static_assert(D % 16 == 0 && D <= 128, "head_dim: a multiple of 16, at most 128");
+  constexpr int QT = VA_QT * QG;               // query rows per workgroup
   constexpr int NCH = D / 8;                   // 16-byte pieces per row
   constexpr int DK = (D + 31) / 32 * 32;       // contraction length of the QK product (zero padded)
   constexpr int NKS = DK / 32;                 // QK MFMA steps
@@ -121,28 +124,30 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   const int seg = lid / (p.tiles_per_seg * p.H);
   const int seg0 = p.cu[seg];
   const int len = p.cu[seg + 1] - seg0;
-  if (tile * VA_QT >= len) return;             // workgroup-uniform (before any barrier)
+  if (tile * QT >= len) return;                // workgroup-uniform (before any barrier)
 
-  const int row = tile * VA_QT + wave * 16 + l15;          // query row inside the segment
-  const bool row_ok = row < len;
-  const long long tok_q = seg0 + (row_ok ? row : len - 1);
-
+  bool row_ok[QG];
+  long long tok_q[QG];
   // ---- Q fragments (B operand of S^T = K Q^T): lane = query row, k-slots 8g..8g+7 of each 32-chunk -----------------
-  u32x4 qf[NKS];
-  {
-    const bf16_t* qp = p.q + tok_q * p.q_st + (long long)h * p.q_sh;
+  u32x4 qf[QG][NKS];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const int row = tile * QT + (wave * QG + qg) * 16 + l15;          // query row inside the segment
+    row_ok[qg] = row < len;
+    tok_q[qg] = seg0 + (row_ok[qg] ? row : len - 1);
+    const bf16_t* qp = p.q + tok_q[qg] * p.q_st + (long long)h * p.q_sh;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int ch = 4 * ks + g;
       if (ch < NCH) {
-        qf[ks] = *(const u32x4*)(qp + ch * 8);
+        qf[qg][ks] = *(const u32x4*)(qp + ch * 8);
         if (p.rcos != nullptr) {
           const int pch = ch < NCH / 2 ? ch + NCH / 2 : ch - NCH / 2;
           const u32x4 part = *(const u32x4*)(qp + pch * 8);
-          qf[ks] = vision_rope_piece(qf[ks], part, p.rcos + tok_q * D + ch * 8, p.rsin + tok_q * D + ch * 8, ch < NCH / 2);
+          qf[qg][ks] = vision_rope_piece(qf[qg][ks], part, p.rcos + tok_q[qg] * D + ch * 8, p.rsin + tok_q[qg] * D + ch * 8, ch < NCH / 2);
         }
       } else {
-        qf[ks] = u32x4{0u, 0u, 0u, 0u};
+        qf[qg][ks] = u32x4{0u, 0u, 0u, 0u};
       }
     }
   }
@@ -154,10 +159,15 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
       *(u32x4*)(smem + (i / NPAD) * KS + (((NCH + i % NPAD) ^ ((i / NPAD) & 15)) << 4)) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4 oacc[NDT];
+  float m_run[QG], l_run[QG];
+  f32x4 oacc[QG][NDT];
 #pragma unroll
-  for (int i = 0; i < NDT; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = -INFINITY;
+    l_run[qg] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) oacc[qg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- staging: thread -> rows (tid >> 4) + 16 i, 16-byte piece tid & 15 (pieces >= NCH idle) ---------------------
   const int srow = tid >> 4, schunk = tid & 15;
@@ -225,62 +235,69 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
     IVL_T(t2);
 
     // ---- S^T = K Q^T : 4 key sub-tiles x NKS channel steps -----------------------------------------------------
-    f32x4 sacc[4];
+    f32x4 sacc[QG][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) sacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sacc[qg][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const u32x4 kf = *(const u32x4*)(smem + (16 * mt + l15) * KS + (((4 * ks + g) ^ l15) << 4));
-        sacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_mfma(kf), va_mfma(qf[ks]), sacc[mt], 0, 0, 0);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+          sacc[qg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_mfma(kf), va_mfma(qf[qg][ks]), sacc[qg][mt], 0, 0, 0);
       }
     if (kt + 1 < n_kt) load_tile(kt + 1);      // lands under the softmax and the PV product
     IVL_T(t3);
 
     // ---- tail mask + online softmax (lane-local rows): lane (g, l15) register r of sub-tile mt <-> key 16 mt + 4 g + r --
-    if (kt * VA_KT + VA_KT > len) {
-      const int jbase = kt * VA_KT + 4 * g;
+    u32x4 pf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      if (kt * VA_KT + VA_KT > len) {
+        const int jbase = kt * VA_KT + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[qg][mt][r] = jbase + 16 * mt + r < len ? sacc[qg][mt][r] : -INFINITY;
+      }
+      // the FIRST reader of the MFMA results is an instruction the compiler sees (its hazard recognizer does not look
+      // inside inline asm; see swa.hip)
+      float rmax = va_max2(__builtin_fmaxf(sacc[qg][0][0], sacc[qg][0][1]), sacc[qg][0][2]);
+      rmax = va_max3(rmax, sacc[qg][0][3], sacc[qg][1][0]);
+      rmax = va_max3(rmax, sacc[qg][1][1], sacc[qg][1][2]);
+      rmax = va_max3(rmax, sacc[qg][1][3], sacc[qg][2][0]);
+      rmax = va_max3(rmax, sacc[qg][2][1], sacc[qg][2][2]);
+      rmax = va_max3(rmax, sacc[qg][2][3], sacc[qg][3][0]);
+      rmax = va_max3(rmax, sacc[qg][3][1], sacc[qg][3][2]);
+      rmax = va_max2(rmax, sacc[qg][3][3]);
+      rmax = va_group_max(rmax) * sc;                          // sc > 0: max commutes with the scale
+      const float m_new = va_max2(m_run[qg], rmax);            // every tile holds at least one valid key: finite
+      float rsum = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[mt][r] = jbase + 16 * mt + r < len ? sacc[mt][r] : -INFINITY;
-    }
-    // the FIRST reader of the MFMA results is an instruction the compiler sees (its hazard recognizer does not look
-    // inside inline asm; see swa.hip)
-    float rmax = va_max2(__builtin_fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
-    rmax = va_max3(rmax, sacc[0][3], sacc[1][0]);
-    rmax = va_max3(rmax, sacc[1][1], sacc[1][2]);
-    rmax = va_max3(rmax, sacc[1][3], sacc[2][0]);
-    rmax = va_max3(rmax, sacc[2][1], sacc[2][2]);
-    rmax = va_max3(rmax, sacc[2][3], sacc[3][0]);
-    rmax = va_max3(rmax, sacc[3][1], sacc[3][2]);
-    rmax = va_max2(rmax, sacc[3][3]);
-    rmax = va_group_max(rmax) * sc;                          // sc > 0: max commutes with the scale
-    const float m_new = va_max2(m_run, rmax);                // every tile holds at least one valid key: finite
-    float rsum = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][mt][r], sc, -m_new));   // argument <= 0
+          sacc[qg][mt][r] = pv;
+          rsum += pv;
+        }
+      rsum = va_group_sum(rsum);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);        // m_run = -inf -> 0
+      l_run[qg] = l_run[qg] * alpha + rsum;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int i = 0; i < NDT; ++i) oacc[qg][i] *= alpha;
+      m_run[qg] = m_new;
+      // P^T fragments (B operand): slots 8g+e <-> keys 32 ks2 + 4g + e | 32 ks2 + 16 + 4g + (e - 4)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][r], sc, -m_new));   // argument <= 0
-        sacc[mt][r] = pv;
-        rsum += pv;
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        pf[qg][ks2].x = pack2bf(sacc[qg][2 * ks2][0], sacc[qg][2 * ks2][1]);
+        pf[qg][ks2].y = pack2bf(sacc[qg][2 * ks2][2], sacc[qg][2 * ks2][3]);
+        pf[qg][ks2].z = pack2bf(sacc[qg][2 * ks2 + 1][0], sacc[qg][2 * ks2 + 1][1]);
+        pf[qg][ks2].w = pack2bf(sacc[qg][2 * ks2 + 1][2], sacc[qg][2 * ks2 + 1][3]);
       }
-    rsum = va_group_sum(rsum);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);            // m_run = -inf -> 0
-    l_run = l_run * alpha + rsum;
-#pragma unroll
-    for (int i = 0; i < NDT; ++i) oacc[i] *= alpha;
-    m_run = m_new;
-    // P^T fragments (B operand): slots 8g+e <-> keys 32 ks2 + 4g + e | 32 ks2 + 16 + 4g + (e - 4)
-    u32x4 pf[2];
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-      pf[ks2].x = pack2bf(sacc[2 * ks2][0], sacc[2 * ks2][1]);
-      pf[ks2].y = pack2bf(sacc[2 * ks2][2], sacc[2 * ks2][3]);
-      pf[ks2].z = pack2bf(sacc[2 * ks2 + 1][0], sacc[2 * ks2 + 1][1]);
-      pf[ks2].w = pack2bf(sacc[2 * ks2 + 1][2], sacc[2 * ks2 + 1][3]);
     }
     IVL_T(t4);
     // ---- O^T += V^T P^T : NDT column tiles x 2 key steps ------------------------------------------------------
@@ -298,7 +315,10 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
         u32x2 w0, w1;
         __builtin_memcpy(&w0, &a0, 8);
         __builtin_memcpy(&w1, &a1, 8);
-        oacc[mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_mfma(u32x4{w0.x, w0.y, w1.x, w1.y}), va_mfma(pf[ks2]), oacc[mt2], 0, 0, 0);
+        const u32x4 vf = u32x4{w0.x, w0.y, w1.x, w1.y};
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+          oacc[qg][mt2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va_mfma(vf), va_mfma(pf[qg][ks2]), oacc[qg][mt2], 0, 0, 0);
       }
     IVL_T(t5);
     IVL_TACC(tv_b1, t1, t0); IVL_TACC(tv_st, t2, t1); IVL_TACC(tv_qk, t3, t2); IVL_TACC(tv_sm, t4, t3); IVL_TACC(tv_pv, t5, t4);
@@ -307,13 +327,16 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   IVL_TOUT(0, tv_loop - tv_start); IVL_TOUT(1, tv_b1); IVL_TOUT(2, tv_st); IVL_TOUT(3, tv_qk); IVL_TOUT(4, tv_sm); IVL_TOUT(5, tv_pv);
   IVL_TOUT(6, tv_end - tv_start); IVL_TOUT(7, n_kt);
 
-  // ---- epilogue: lane owns its row, channels 16 mt2 + 4 g + r ---------------------------------------------------
-  if (!row_ok) return;
-  const float inv = 1.0f / l_run;              // l_run >= 1 term: the row's own maximum contributes 2^0
-  bf16_t* op = p.o + tok_q * p.o_st + (long long)h * p.o_sh + 4 * g;
+  // ---- epilogue: lane owns its rows, channels 16 mt2 + 4 g + r ---------------------------------------------------
 #pragma unroll
-  for (int mt2 = 0; mt2 < NDT; ++mt2)
-    *(u32x2*)(op + 16 * mt2) = u32x2{pack2bf(oacc[mt2][0] * inv, oacc[mt2][1] * inv), pack2bf(oacc[mt2][2] * inv, oacc[mt2][3] * inv)};
+  for (int qg = 0; qg < QG; ++qg) {
+    if (!row_ok[qg]) continue;
+    const float inv = 1.0f / l_run[qg];        // l_run >= 1 term: the row's own maximum contributes 2^0
+    bf16_t* op = p.o + tok_q[qg] * p.o_st + (long long)h * p.o_sh + 4 * g;
+#pragma unroll
+    for (int mt2 = 0; mt2 < NDT; ++mt2)
+      *(u32x2*)(op + 16 * mt2) = u32x2{pack2bf(oacc[qg][mt2][0] * inv, oacc[qg][mt2][1] * inv), pack2bf(oacc[qg][mt2][2] * inv, oacc[qg][mt2][3] * inv)};
+  }
 }
 
 // Rotary pre-pass for calls whose segments span several 64-row query tiles (the full-attention layers): every key would otherwise be rotated once per query tile of its segment, and the rotation (partner piece + 64
@@ -390,7 +413,9 @@ extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, 
   IVL_REQUIRE(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0 && o_st % 4 == 0 && o_sh % 4 == 0,
               IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: strides must keep 16-byte (q, k, v) / 8-byte (o) alignment");
   IVL_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: misaligned pointer");
-  const int tiles = (max_seqlen + VA_QT - 1) / VA_QT;
+  // 128-row workgroups when that grid still gives every CU two of them; otherwise 64 rows (window layers, single frames)
+  const int qg = (max_seqlen > VA_QT && (long long)n_seg * ((max_seqlen + 2 * VA_QT - 1) / (2 * VA_QT)) * H >= 512) ? 2 : 1;
+  const int tiles = (max_seqlen + VA_QT * qg - 1) / (VA_QT * qg);
   IVL_REQUIRE((long long)n_seg * tiles * H < (1ll << 31), IVL_ERR_UNSUPPORTED, "ivl_vision_attn_fwd: grid too large");
   VisionAttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
@@ -413,8 +438,14 @@ extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, 
     p.q_st = p.k_st = (long long)H * d; p.q_sh = p.k_sh = d;
     p.rcos = p.rsin = nullptr;
   }
-  if (d == 80) hipLaunchKernelGGL((vision_attn_kernel<80>), grid, dim3(256), 0, st, p);
-  else if (d == 64) hipLaunchKernelGGL((vision_attn_kernel<64>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((vision_attn_kernel<128>), grid, dim3(256), 0, st, p);
+  if (qg == 1) {
+    if (d == 80) hipLaunchKernelGGL((vision_attn_kernel<80, 1>), grid, dim3(256), 0, st, p);
+    else if (d == 64) hipLaunchKernelGGL((vision_attn_kernel<64, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((vision_attn_kernel<128, 1>), grid, dim3(256), 0, st, p);
+  } else {
+    if (d == 80) hipLaunchKernelGGL((vision_attn_kernel<80, 2>), grid, dim3(256), 0, st, p);
+    else if (d == 64) hipLaunchKernelGGL((vision_attn_kernel<64, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((vision_attn_kernel<128, 2>), grid, dim3(256), 0, st, p);
+  }
   return check_launch("ivl_vision_attn_fwd");
 }

@@ -380,7 +380,7 @@ def test_vision_attention_real_shapes_vs_oracle(d, H):
     from infinitevl_amd import ops
     torch.manual_seed(5)
     win = [64] * 16 + [64] * 9 + [48] * 6 + [36]                   # 1024 + 900 patches
-    for lens in (win, [1024, 900]):
+    for lens in (win, [1024, 900], [1024, 900, 1000, 1024, 130]):      # the last one (d = 80) runs the 128-row workgroups
         S = sum(lens)
         cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
         qkv = bf(torch.randn(S, 3, H, d))
