@@ -219,7 +219,7 @@ IVL_API int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_fr
  *             bit-identical to the reference's eager arithmetic.
  *   S          : number of tokens (patches) in the packed sequence
  *   workspace  : ivl_vision_attn_workspace_bytes(S, H, d, max_seqlen) bytes (0 when max_seqlen <= 64) or NULL.  With rope
- *             tables and segments longer than one 64-row query tile, q and k are rotated ONCE into it by a pre-pass;
+ *             tables and segments longer than one 64-row query tile, the keys are rotated ONCE into it by a pre-pass;
  *             without it the rotation is redone in every query tile's loads (same results, slower).
  * Scores and the softmax statistics are fp32, the probabilities are rounded to bf16 for the PV product, fp32 accumulation. */
 IVL_API size_t ivl_vision_attn_workspace_bytes(int S, int H, int d, int max_seqlen);

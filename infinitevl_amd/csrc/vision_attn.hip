@@ -33,6 +33,7 @@ struct VisionAttnParams {
   long long q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh;      // element strides: token, head
   const int* cu; int n_seg, tiles_per_seg, H;
   const float* rcos; const float* rsin;                          // [S, D] fp32 or NULL (inputs already rotated)
+  int k_rotated;                                                 // the keys come from the rotary pre-pass: only q is rotated in the kernel
   float scaling;
 };
 
@@ -176,12 +177,13 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
   const bf16_t* kb = p.k + (long long)h * p.k_sh;
   const bf16_t* vb = p.v + (long long)h * p.v_sh;
   u32x4 kreg[4], vreg[4];
+  const bool rope_k = p.rcos != nullptr && !p.k_rotated;
   const bf16_t* kp0 = kb + (long long)(seg0 + srow) * p.k_st + schunk * 8;      // this thread's piece of row srow of tile 0
   const bf16_t* vp0 = vb + (long long)(seg0 + srow) * p.v_st + schunk * 8;
   const long long k16 = 16 * p.k_st, v16 = 16 * p.v_st;
   auto load_tile = [&](int kt) {
     if (!s_act) return;
-    if (p.rcos == nullptr && kt * VA_KT + VA_KT <= len) {
+    if (!rope_k && kt * VA_KT + VA_KT <= len) {
       // workgroup-uniform fast path (every tile but the last of a segment, keys already rotated): eight loads off two
       // running pointers, nothing here reads the loaded values (a per-row select or the rotation would make the tile
       // wait for its loads on the spot instead of at the LDS store one iteration later)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
       const bf16_t* kp = kb + tok * p.k_st;
       kreg[i] = *(const u32x4*)(kp + schunk * 8);
       vreg[i] = *(const u32x4*)(vb + tok * p.v_st + schunk * 8);
-      if (p.rcos != nullptr) {
+      if (rope_k) {
         const u32x4 part = *(const u32x4*)(kp + spart * 8);
         kreg[i] = vision_rope_piece(kreg[i], part, p.rcos + tok * D + schunk * 8, p.rsin + tok * D + schunk * 8, schunk < NCH / 2);
       }
@@ -285,10 +287,14 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
           rsum += pv;
         }
       rsum = va_group_sum(rsum);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);        // m_run = -inf -> 0
-      l_run[qg] = l_run[qg] * alpha + rsum;
+      if (__any(m_new > m_run[qg])) {                          // some row's running maximum moved: rescale (exact)
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);      // m_run = -inf -> 0
+        l_run[qg] = l_run[qg] * alpha + rsum;
 #pragma unroll
-      for (int i = 0; i < NDT; ++i) oacc[qg][i] *= alpha;
+        for (int i = 0; i < NDT; ++i) oacc[qg][i] *= alpha;
+      } else {
+        l_run[qg] += rsum;
+      }
       m_run[qg] = m_new;
       // P^T fragments (B operand): slots 8g+e <-> keys 32 ks2 + 4g + e | 32 ks2 + 16 + 4g + (e - 4)
 #pragma unroll
@@ -340,9 +346,10 @@ __global__ __launch_bounds__(256, 2) void vision_attn_kernel(VisionAttnParams p)
 }
 
 // Rotary pre-pass for calls whose segments span several 64-row query tiles (the full-attention layers): every key would otherwise be rotated once per query tile of its segment, and the rotation (partner piece + 64
-// bytes of tables per piece) sits between a tile's loads and its LDS store.  One thread per (q | k, token, group of 4 heads,
+// bytes of tables per piece) sits between a tile's loads and its LDS store.  Only the KEYS take the extra trip through HBM:
+// a query row is used by one workgroup only and stays rotated in its prologue.  One thread per (token, group of 4 heads,
 // pair of 16-byte pieces D/2 channels apart): the 4 x 32 bytes of tables are loaded once and serve 4 heads x both pieces of
-// the pair (each piece is the other's rotate_half partner)  ->  [2][S][H][D] bf16.
+// the pair (each piece is the other's rotate_half partner)  ->  [S][H][D] bf16.
 template <int D>
 __global__ __launch_bounds__(256) void vision_rope_prepass_kernel(VisionAttnParams p, bf16_t* __restrict__ out, int S, int H) {
 #pragma clang fp contract(off)
@@ -350,9 +357,8 @@ __global__ __launch_bounds__(256) void vision_rope_prepass_kernel(VisionAttnPara
   const int hg = (H + 3) / 4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)S * hg * NP;
-  if (idx >= 2 * n) return;
-  const int which = idx >= n;
-  const long long r = which ? idx - n : idx;
+  if (idx >= n) return;
+  const long long r = idx;
   const int pr = (int)(r % NP);
   const int h0 = (int)((r / NP) % hg) * 4;
   const long long tok = r / ((long long)NP * hg);
@@ -364,9 +370,9 @@ __global__ __launch_bounds__(256) void vision_rope_prepass_kernel(VisionAttnPara
   const float c_hi[8] = {ch0[0], ch0[1], ch0[2], ch0[3], ch1[0], ch1[1], ch1[2], ch1[3]};
   const float s_lo[8] = {sl0[0], sl0[1], sl0[2], sl0[3], sl1[0], sl1[1], sl1[2], sl1[3]};
   const float s_hi[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
-  const bf16_t* src = (which ? p.k + tok * p.k_st : p.q + tok * p.q_st) + pr * 8;
-  const long long sh = which ? p.k_sh : p.q_sh;
-  bf16_t* dst = out + ((which * (long long)S + tok) * H) * D + pr * 8;
+  const bf16_t* src = p.k + tok * p.k_st + pr * 8;
+  const long long sh = p.k_sh;
+  bf16_t* dst = out + (tok * H) * D + pr * 8;
   u32x4 lo[4], hi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -398,7 +404,7 @@ extern "C" size_t ivl_vision_attn_workspace_bytes(int S, int H, int d, int max_s
   // one query tile per segment (window layers): nothing is rotated twice, the rotation stays in the tile loads (a pre-pass
   // is a second trip of q and k through HBM: 36 vs 31 us on 8 frames of a window layer)
   if (S <= 0 || H <= 0 || d <= 0 || max_seqlen <= VA_QT) return 0;
-  return (size_t)2 * S * H * d * sizeof(bf16_t);
+  return (size_t)S * H * d * sizeof(bf16_t);            // the rotated keys
 }
 
 extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, void* o,
@@ -421,22 +427,22 @@ extern "C" int ivl_vision_attn_fwd(const void* q, const void* k, const void* v, 
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.q_st = q_st; p.q_sh = q_sh; p.k_st = k_st; p.k_sh = k_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
   p.cu = cu_seqlens; p.n_seg = n_seg; p.tiles_per_seg = tiles; p.H = H;
-  p.rcos = rope_cos; p.rsin = rope_sin; p.scaling = scaling;
+  p.rcos = rope_cos; p.rsin = rope_sin; p.scaling = scaling; p.k_rotated = 0;
   const dim3 grid(n_seg * tiles * H);
   hipStream_t st = (hipStream_t)stream;
   const size_t ws_need = ivl_vision_attn_workspace_bytes(S, H, d, max_seqlen);
   if (rope_cos != nullptr && ws_need > 0 && workspace != nullptr && workspace_bytes >= ws_need) {
-    // several query tiles per segment: rotate q and k once (without a workspace the rotation stays in the tile loads:
+    // several query tiles per segment: rotate the keys once (without a workspace the rotation stays in the tile loads:
     // correct, but redone per query tile)
-    const long long work = 2ll * S * ((H + 3) / 4) * (d / 16);
+    const long long work = (long long)S * ((H + 3) / 4) * (d / 16);
     const dim3 pg((unsigned int)((work + 255) / 256));
     bf16_t* ws = (bf16_t*)workspace;
     if (d == 80) hipLaunchKernelGGL((vision_rope_prepass_kernel<80>), pg, dim3(256), 0, st, p, ws, S, H);
     else if (d == 64) hipLaunchKernelGGL((vision_rope_prepass_kernel<64>), pg, dim3(256), 0, st, p, ws, S, H);
     else hipLaunchKernelGGL((vision_rope_prepass_kernel<128>), pg, dim3(256), 0, st, p, ws, S, H);
-    p.q = ws; p.k = ws + (size_t)S * H * d;
-    p.q_st = p.k_st = (long long)H * d; p.q_sh = p.k_sh = d;
-    p.rcos = p.rsin = nullptr;
+    p.k = ws;
+    p.k_st = (long long)H * d; p.k_sh = d;
+    p.k_rotated = 1;
   }
   if (qg == 1) {
     if (d == 80) hipLaunchKernelGGL((vision_attn_kernel<80, 1>), grid, dim3(256), 0, st, p);
