@@ -1,11 +1,13 @@
 /*
  * ivl_hip.h -- C ABI of libivl_hip.so: MI355X (gfx950 / CDNA4) kernels for the
- * InfiniteVL hybrid-attention hot path (Gated DeltaNet + sliding-window attention).
+ * InfiniteVL hybrid-attention hot path (Gated DeltaNet + sliding-window attention, and the
+ * vision tower's window attention).
  *
  * This is the drop-in boundary.  Each entry point replaces one
  * operator the reference reaches through a third-party CUDA/Triton package; the
  * reference call site it serves is cited as `std:<line>` =
- * infinitevl/infinitevl_standard/modeling_infinitevl.py and `fla:` =
+ * infinitevl/infinitevl_standard/modeling_infinitevl.py, `strm:` = the same file of
+ * infinitevl/infinitevl_streaming/, and `fla:` =
  * src/llamafactory/model/fla/ (vendored snapshot of flash-linear-attention).
  *
  * Conventions
