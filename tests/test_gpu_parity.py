@@ -436,6 +436,52 @@ def test_vision_attention_is_graph_capturable_and_rejects_bad_arguments():
         ops.vision_window_attention(q[..., :48].contiguous(), k[..., :48].contiguous(), v[..., :48].contiguous(), cu, 72)
 
 
+def test_hot_kernels_are_bit_stable_from_run_to_run():
+    """Every kernel of the path is deterministic by construction (no atomics on data, fixed reduction orders), so the same
+    inputs must give the same bits on every launch.  This is the test that catches what parity tolerances hide: a missing
+    wait state after an MFMA (the attention kernels once read accumulators one instruction early: 1-ulp differences in
+    8-15 % of the outputs from run to run), an LDS race, a DMA awaited by the wrong count."""
+    from infinitevl_amd import ops
+    torch.manual_seed(11)
+    dev = DEV
+    runs = []
+    # chunk rule (pre-pass + scan, bf16 and e4m3 operands), with and without a carried state
+    for T, B in ((256, 1), (1000, 2)):
+        q, k = (bf(torch.randn(B, T, 16, 128)).to(dev) for _ in range(2))
+        v = bf(torch.randn(B, T, 16, 256)).to(dev)
+        g = torch.nn.functional.logsigmoid(torch.randn(B, T, 16)).to(dev)
+        beta = bf(torch.rand(B, T, 16)).to(dev)
+        h0 = torch.randn(B, 16, 128, 256).to(dev)
+        for mma in ("bf16", "fp8_e4m3"):
+            runs.append((f"gdn_chunk T={T} {mma}", lambda q=q, k=k, v=v, g=g, beta=beta, h0=h0, mma=mma: ops.chunk_gated_delta_rule(
+                q, k, v, g, beta, initial_state=h0, output_final_state=True, use_qk_l2norm_in_kernel=True, mma_dtype=mma)))
+    # attention: split-KV step over a full ring, one-split long causal call, decode row
+    W = 4096
+    kc, vc = (bf(torch.randn(1, 2, W - 1, 128)).to(dev) for _ in range(2))
+    pos = torch.full((1,), 3 * W + 17, dtype=torch.int64, device=dev)
+    for T in (256, 1):
+        qs = bf(torch.randn(1, T, 16, 128)).to(dev)
+        kn, vn = (bf(torch.randn(1, T, 2, 128)).to(dev) for _ in range(2))
+        runs.append((f"swa ring T={T}", lambda qs=qs, kn=kn, vn=vn: (ops.swa_forward(qs, kn, vn, window=W, scaling=128 ** -0.5,
+                                                                                    k_cache=kc, v_cache=vc, pos_dev=pos),)))
+    qs = bf(torch.randn(1, 2048, 16, 128)).to(dev)
+    kn, vn = (bf(torch.randn(1, 2048, 2, 128)).to(dev) for _ in range(2))
+    runs.append(("swa causal T=2048", lambda: (ops.swa_forward(qs, kn, vn, window=8192, scaling=128 ** -0.5),)))
+    # vision attention: window layer, full layer (128-row workgroups + key pre-pass)
+    qkv = bf(torch.randn(4096, 3, 16, 80)).to(dev)
+    tabs = tuple(torch.randn(4096, 80, device=dev) for _ in range(2))
+    for seg in (64, 1024):
+        cu = torch.arange(0, 4097, seg, dtype=torch.int32, device=dev)
+        runs.append((f"vision seg={seg}", lambda cu=cu, seg=seg: (ops.vision_window_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg,
+                                                                                             rope=tabs),)))
+    for name, fn in runs:
+        first = [t.clone() for t in fn() if t is not None]
+        for rep in range(6):
+            again = [t for t in fn() if t is not None]
+            for a_, b_ in zip(first, again):
+                assert torch.equal(a_, b_), (name, rep)
+
+
 def _band_counts(n_prev, T, W):
     """Decode WHICH keys each row attended: q = 0 makes the softmax uniform over the visible set, V holds
     one-hot residues of the key index, so out[i, r] * n_vis(i) = #visible keys with residue r.  Two encodings: j % 128
