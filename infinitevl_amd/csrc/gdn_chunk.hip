@@ -161,36 +161,46 @@ struct PrepFused {
 // path's tensors are bf16).
 template <int NR>
 __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x4* out) {
+  // two channels per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32; component-wise IEEE, so the results are those
+  // of the scalar form): the front end of a 64-token chunk is ~9,000 VALU cycles per SIMD, half of them the two
+  // transcendentals of the SiLU, which have no packed form
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const unsigned int ww[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
                                w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
-  float wf[8][4];
+  f32x2 wf[4][4];                                   // [channel pair][tap]
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    wf[c][0] = bflo(ww[2 * c]); wf[c][1] = bfhi(ww[2 * c]); wf[c][2] = bflo(ww[2 * c + 1]); wf[c][3] = bfhi(ww[2 * c + 1]);
+  for (int c2 = 0; c2 < 4; ++c2) {
+    const int c = 2 * c2;
+    wf[c2][0] = f32x2{bflo(ww[2 * c]), bflo(ww[2 * c + 2])};
+    wf[c2][1] = f32x2{bfhi(ww[2 * c]), bfhi(ww[2 * c + 2])};
+    wf[c2][2] = f32x2{bflo(ww[2 * c + 1]), bflo(ww[2 * c + 3])};
+    wf[c2][3] = f32x2{bfhi(ww[2 * c + 1]), bfhi(ww[2 * c + 3])};
   }
-  float win[3][8];
+  auto unpack = [](const u32x4 x, f32x2* d) {
+    d[0] = f32x2{bflo(x.x), bfhi(x.x)}; d[1] = f32x2{bflo(x.y), bfhi(x.y)};
+    d[2] = f32x2{bflo(x.z), bfhi(x.z)}; d[3] = f32x2{bflo(x.w), bfhi(x.w)};
+  };
+  f32x2 win[3][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const u32x4 x = xr[k];
-    win[k][0] = bflo(x.x); win[k][1] = bfhi(x.x); win[k][2] = bflo(x.y); win[k][3] = bfhi(x.y);
-    win[k][4] = bflo(x.z); win[k][5] = bfhi(x.z); win[k][6] = bflo(x.w); win[k][7] = bfhi(x.w);
-  }
+  for (int k = 0; k < 3; ++k) unpack(xr[k], win[k]);
+  const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const u32x4 x = xr[k + 3];
-    const float cur[8] = {bflo(x.x), bfhi(x.x), bflo(x.y), bfhi(x.y), bflo(x.z), bfhi(x.z), bflo(x.w), bfhi(x.w)};
-    float o[8];
+    f32x2 cur[4], o[4];
+    unpack(xr[k + 3], cur);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float a = wf[c][0] * win[0][c];
-      a = fmaf(wf[c][1], win[1][c], a);
-      a = fmaf(wf[c][2], win[2][c], a);
-      a = fmaf(wf[c][3], cur[c], a);
-      a = a * sigmoidf_(a);
-      o[c] = a;
-      win[0][c] = win[1][c]; win[1][c] = win[2][c]; win[2][c] = cur[c];
+    for (int c2 = 0; c2 < 4; ++c2) {
+      f32x2 a = wf[c2][0] * win[0][c2];
+      a = __builtin_elementwise_fma(wf[c2][1], win[1][c2], a);
+      a = __builtin_elementwise_fma(wf[c2][2], win[2][c2], a);
+      a = __builtin_elementwise_fma(wf[c2][3], cur[c2], a);
+      // a * sigmoid(a), sigmoid = rcp(1 + 2^(-a log2 e)) as in sigmoidf_ (ivl_common.h)
+      f32x2 e = a * nl2e;
+      e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + one;
+      o[c2] = a * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+      win[0][c2] = win[1][c2]; win[1][c2] = win[2][c2]; win[2][c2] = cur[c2];
     }
-    out[k] = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    out[k] = u32x4{pack2bf(o[0][0], o[0][1]), pack2bf(o[1][0], o[1][1]), pack2bf(o[2][0], o[2][1]), pack2bf(o[3][0], o[3][1])};
   }
 }
 
@@ -212,6 +222,9 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   float* s_beta = s_dec + GC;
 
   IVL_T(tp0);
+#ifdef IVL_TRACE
+  const unsigned long long rt_p0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int l31 = lane & 31, hi = lane >> 5;
@@ -680,6 +693,15 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
   }
   IVL_T(tp4);
+#ifdef IVL_TRACE
+  // spread over the workgroups of the launch on the shared 100 MHz clock: first start (slot 26), last end (27), longest (28)
+  if (ivl_trace_buf != nullptr && threadIdx.x == 0) {
+    const unsigned long long rt_p1 = __builtin_amdgcn_s_memrealtime();
+    atomicMin((unsigned long long*)ivl_trace_buf + 26, rt_p0);
+    atomicMax((unsigned long long*)ivl_trace_buf + 27, rt_p1);
+    atomicMax((unsigned long long*)ivl_trace_buf + 28, rt_p1 - rt_p0);
+  }
+#endif
   IVL_TOUT(0, tp0); IVL_TOUT(1, tp1 - tp0); IVL_TOUT(2, tp2 - tp1); IVL_TOUT(3, tp3a - tp2); IVL_TOUT(4, tp3b - tp3a);
   IVL_TOUT(5, tp3 - tp3b); IVL_TOUT(6, tp4 - tp3); IVL_TOUT(7, tp4);
 }

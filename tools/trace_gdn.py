@@ -36,11 +36,13 @@ lib.ivl_debug_set_trace(ctypes.c_void_p(trace.data_ptr()))
 NT = (T + 63) // 64
 for it in range(3):
     trace.zero_()
+    trace[26] = 2 ** 62
     run()
     torch.cuda.synchronize()
     t = trace.cpu().tolist()
     print(f"--- iter {it}: prepare (cycles): load+l2norm {t[1]} | L,A mfma {t[2]} | solve L0 {t[3]} L1 {t[4]} L2 {t[5]} | Tu,w {t[6]} "
           f"| total {t[7]-t[0]}")
+    print(f"    prepare launch on the 100 MHz clock: first workgroup start -> last end {(t[27]-t[26]) * 10} ns, longest workgroup {t[28] * 10} ns")
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
           f"| scan realtime ticks {t[25]} -> {(t[22]-t[16]) / max(t[25], 1) * 100:.0f} MHz if the tick is 100 MHz")
