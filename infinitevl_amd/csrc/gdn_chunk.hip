@@ -245,7 +245,28 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   u32x4 kraw[NQK], qraw[NQK];
   bf16_t braw[NQK];
   u32x4 vraw[8];                                     // waves 4-7: the chunk's v tile, 8 x 16 bytes per thread
-  const int t2v = tid - 256, voct = t2v & 31, vr = t2v >> 5;
+  // SIMD s hosts waves s and s + 4.  Three pieces of single-wave work sit in front of B1: the conv-state hand-over of q / k
+  // (the threads that hold rows 0-3: wave 0), the hand-over of v (the threads with vr == 0) and the gate / cumsum step P1a.
+  // All three on SIMD 0 (waves 0 and 4) made that SIMD arrive at B1 5,500 cycles after the others; now P1a runs on wave 1
+  // and the v run that starts at row 0 belongs to wave 7.
+  const int t2v = tid - 256, voct = t2v & 31, vr = ((t2v >> 5) + 2) & 7;
+  constexpr int P1A_WAVE = 1;
+  // wave 0 also fetches the chunk's gate inputs here (consumed in P1a, behind its conv work: requested there they were a
+  // memory round trip of their own on the wave every other one waits for at B1)
+  float p1_g = 0.f, p1_b = 0.f, p1_dt = 0.f, p1_A = 0.f;
+  if (wave_u == P1A_WAVE) {
+    const size_t tok1 = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
+    if constexpr (FUSED) {
+      const bf16_t* row = pf.proj + ((size_t)b * T + t0 + min(lane, nvalid - 1)) * pf.ld;
+      p1_g = bf2f(row[pf.col_a + h]);
+      p1_b = bf2f(row[pf.col_b + h]);
+      p1_dt = pf.dt_bias[h];
+      p1_A = pf.A_log[h];
+    } else {
+      p1_g = g[tok1];
+      p1_b = bf2f(beta[tok1]);
+    }
+  }
   auto qk_row = [&](int rr) { return FUSED ? 4 * r0 + rr : r0 + 32 * rr; };
   auto v_row = [&](int i) { return FUSED ? 8 * vr + i : vr + 8 * i; };
   if constexpr (!FUSED) {
@@ -279,24 +300,30 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
     };
     // the history of a run that starts at time 0 is the conv state: state[c][1..3] = times -3, -2, -1
-    auto history = [&](u32x4* xr, const bf16_t* st_in, int dch) {
-      u32x4 s4[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    // (the state is REQUESTED by history_load together with the run's own loads and only consumed by history: requested
+    // where it is consumed it costs the workgroup that holds time 0 - the one every launch waits for - a second full
+    // memory round trip, ~3,400 cycles)
+    auto history_load = [&](u32x4* s4, const bf16_t* st_in, int dch) {
+      s4[0] = s4[1] = s4[2] = s4[3] = u32x4{0u, 0u, 0u, 0u};
       if (st_in != nullptr) {
         const u32x4* sp = (const u32x4*)(st_in + ((size_t)b * H * (dch == 2 ? GV : GK) + (size_t)h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct)) * 4);
         s4[0] = sp[0]; s4[1] = sp[1]; s4[2] = sp[2]; s4[3] = sp[3];
       }
+    };
+    auto history = [&](u32x4* xr, const u32x4* s4) {
       const unsigned int ss[16] = {s4[0].x, s4[0].y, s4[0].z, s4[0].w, s4[1].x, s4[1].y, s4[1].z, s4[1].w,
                                    s4[2].x, s4[2].y, s4[2].z, s4[2].w, s4[3].x, s4[3].y, s4[3].z, s4[3].w};
-      // channel c: ss[2c] = (state[c][0], state[c][1]), ss[2c + 1] = (state[c][2], state[c][3])
+      // channel c: ss[2c] = (state[c][0], state[c][1]), ss[2c + 1] = (state[c][2], state[c][3]); row kk takes tap kk + 1 of the
+      // eight channels: one v_perm_b32 per pair of channels (the hand-over runs on a few lanes of ONE wave while the whole
+      // workgroup waits at B1, and shares its SIMD with a wave that is converting: every instruction costs ~10 cycles)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
-        unsigned int hw[8];
+        const int w = (kk + 1) >> 1;
+        const unsigned int sel = ((kk + 1) & 1) ? 0x07060302u : 0x05040100u;         // the high | the low halves of (a, b)
+        unsigned int d[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const unsigned int word = ss[2 * c + ((kk + 1) >> 1)];
-          hw[c] = ((kk + 1) & 1) ? word >> 16 : word & 0xffffu;
-        }
-        xr[kk] = u32x4{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16)};
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_perm(ss[2 * (2 * j + 1) + w], ss[2 * (2 * j) + w], sel);
+        xr[kk] = u32x4{d[0], d[1], d[2], d[3]};
       }
     };
     // new conv state = the last four inputs of the sequence ([old state, x] when T < 4): written by the thread that read
@@ -314,10 +341,15 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       if (st_out == nullptr) return;
       const int D = H * (dch == 2 ? GV : GK), d0 = h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct);
       u32x4 row[4];
+      if (T >= 4) {                                                    // (uniform) the last four inputs, as loaded
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = T + j;                                           // e >= 4: x[e - 4]; e = 1..3 (T < 4): old state[.][e]
-        row[j] = e >= 4 ? tail[j] : (e == 1 ? hist3[0] : (e == 2 ? hist3[1] : hist3[2]));
+        for (int j = 0; j < 4; ++j) row[j] = tail[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = T + j;                                         // e >= 4: x[e - 4]; e = 1..3 (T < 4): old state[.][e]
+          row[j] = e >= 4 ? tail[j] : (e == 1 ? hist3[0] : (e == 2 ? hist3[1] : hist3[2]));
+        }
       }
       // row[j] holds (channel 0..7) of ext[T + j]; the state is [channel][4 taps]: transpose 4 x 8 halfwords
       const unsigned int r0w[4] = {row[0].x, row[0].y, row[0].z, row[0].w}, r1w[4] = {row[1].x, row[1].y, row[1].z, row[1].w};
@@ -325,8 +357,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       u32x4* op = (u32x4*)(st_out + ((size_t)b * D + d0) * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                                    // channels 2i, 2i + 1
-        const unsigned int lo01 = (r0w[i] & 0xffffu) | (r1w[i] << 16), lo23 = (r2w[i] & 0xffffu) | (r3w[i] << 16);
-        const unsigned int hi01 = (r0w[i] >> 16) | (r1w[i] & 0xffff0000u), hi23 = (r2w[i] >> 16) | (r3w[i] & 0xffff0000u);
+        const unsigned int lo01 = __builtin_amdgcn_perm(r1w[i], r0w[i], 0x05040100u), lo23 = __builtin_amdgcn_perm(r3w[i], r2w[i], 0x05040100u);
+        const unsigned int hi01 = __builtin_amdgcn_perm(r1w[i], r0w[i], 0x07060302u), hi23 = __builtin_amdgcn_perm(r3w[i], r2w[i], 0x07060302u);
         op[i] = u32x4{lo01, lo23, hi01, hi23};
       }
     };
@@ -340,23 +372,37 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const u32x4* wkp = (const u32x4*)(pf.w[1] + ((size_t)h * GK + 8 * oct) * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { wq[i] = wqp[i]; wk[i] = wkp[i]; }
+      bf16_t bin[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {                                 // beta = bf16(sigmoid(b)) (std:1293)
+      for (int rr = 0; rr < 4; ++rr) {
         const int tg = min(t0 + 4 * r0 + rr, T - 1);
-        const float bv = bf2f(xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)]);
-        braw[rr] = f2bf(sigmoidf_(bv));
+        bin[rr] = xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)];
       }
+      // every load of the thread is in flight before the first one is consumed (in-order return: waiting for any of them
+      // waits for all issued before it)
+      u32x4 tq[4], tk[4], sq4[4], sk4[4];
       if (own_state && r0 == 0) {
-        u32x4 tq[4], tk[4];
         tail_load(tq, cq);
         tail_load(tk, ck);
-        history(xq, pf.st_in[0], 0);
-        history(xk, pf.st_in[1], 1);
+        history_load(sq4, pf.st_in[0], 0);
+        history_load(sk4, pf.st_in[1], 1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoidf_(bf2f(bin[rr])));          // beta = bf16(sigmoid(b)) (std:1293)
+      IVL_T(tf0);
+      IVL_TOUT(8, tf0 - tp0);
+      if (own_state && r0 == 0) {
+        history(xq, sq4);
+        history(xk, sk4);
         put_state(tq, xq, pf.st_out[0], 0);
         put_state(tk, xk, pf.st_out[1], 1);
       }
+      IVL_T(tf1);
       conv4_silu<4>(xq, wq, qraw);
+      IVL_T(tf2);
       conv4_silu<4>(xk, wk, kraw);
+      IVL_T(tf3);
+      IVL_TOUT(9, tf1 - tf0); IVL_TOUT(10, tf2 - tf1); IVL_TOUT(11, tf3 - tf2);
     } else {
       u32x4 xv[11], wv[4];
       const int cv = pf.col_v + h * GV + 8 * voct;
@@ -364,29 +410,31 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const u32x4* wvp = (const u32x4*)(pf.w[2] + ((size_t)h * GV + 8 * voct) * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) wv[i] = wvp[i];
+      IVL_T(tv0);
       if (own_state && vr == 0) {
-        u32x4 tv[4];
+        u32x4 tv[4], sv4[4];
         tail_load(tv, cv);
-        history(xv, pf.st_in[2], 2);
+        history_load(sv4, pf.st_in[2], 2);
+        history(xv, sv4);
         put_state(tv, xv, pf.st_out[2], 2);
       }
+      IVL_T(tv1);
       conv4_silu<8>(xv, wv, vraw);
+      IVL_T(tv2);
+      IVL_TOUT_AT(448, 12, tv0 - tp0); IVL_TOUT_AT(448, 13, tv1 - tv0); IVL_TOUT_AT(448, 14, tv2 - tv1);
     }
   }
-  // ---- P1a (wave 0): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta ---------------
-  if (wave_u == 0) {
-    const size_t tok = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
+  // ---- P1a (one wave): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta -------------
+  if (wave_u == P1A_WAVE) {
     float g_ld, b_ld;
     if constexpr (FUSED) {                           // g = -exp(A_log) softplus(a + dt_bias), beta = bf16(sigmoid(b)) (std:1293-1294)
-      const bf16_t* row = pf.proj + ((size_t)b * T + t0 + min(lane, nvalid - 1)) * pf.ld;
-      const float av = bf2f(row[pf.col_a + h]) + pf.dt_bias[h];
-      const float bv = bf2f(row[pf.col_b + h]);
+      const float av = p1_g + p1_dt;
       const float sp = av > 20.f ? av : log1pf(expf(av));
-      g_ld = -expf(pf.A_log[h]) * sp;
-      b_ld = bf2f(f2bf(sigmoidf_(bv)));
+      g_ld = -expf(p1_A) * sp;
+      b_ld = bf2f(f2bf(sigmoidf_(p1_b)));
     } else {
-      g_ld = g[tok];
-      b_ld = bf2f(beta[tok]);
+      g_ld = p1_g;
+      b_ld = p1_b;
     }
     float gv = lane < nvalid ? g_ld : 0.f;
     const float bv = lane < nvalid ? b_ld : 0.f;
@@ -437,6 +485,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     *(u32x4*)(s_qh + row * P_LDK + 8 * oct) = pack8(qf[0], qf[1], qf[2], qf[3], qf[4], qf[5], qf[6], qf[7]);
     *(u32x4*)(s_kb + row * P_LDK + 8 * oct) = pack8(kb[0], kb[1], kb[2], kb[3], kb[4], kb[5], kb[6], kb[7]);
   }
+  IVL_T(tb1);
+  IVL_TOUT(15, tb1 - tp0); IVL_TOUT_AT(448, 29, tb1 - tp0); IVL_TOUT_AT(64, 30, tb1 - tp0);
   __syncthreads();                                   // B1
   IVL_T(tp1);
 

@@ -42,6 +42,8 @@ for it in range(3):
     t = trace.cpu().tolist()
     print(f"--- iter {it}: prepare (cycles): load+l2norm {t[1]} | L,A mfma {t[2]} | solve L0 {t[3]} L1 {t[4]} L2 {t[5]} | Tu,w {t[6]} "
           f"| total {t[7]-t[0]}")
+    print(f"    fused front end (wave 0): loads issued {t[8]} | state hand-over {t[9]} | conv q {t[10]} | conv k {t[11]}")
+    print(f"    v wave 7: loads issued {t[12]} | state hand-over {t[13]} | conv v {t[14]} | arrival at B1: wave 0 {t[15]}, wave 1 {t[30]}, wave 7 {t[29]}")
     print(f"    prepare launch on the 100 MHz clock: first workgroup start -> last end {(t[27]-t[26]) * 10} ns, longest workgroup {t[28] * 10} ns")
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
