@@ -818,15 +818,22 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
       rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
       const float m_new = vmax2(m_run, rmax);
-      m_use = m_new == -INFINITY ? 0.f : m_new;
-      need = __any(m_new > m_run);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_use);     // 1 for a row whose maximum did not move, 0 for a first tile
-      m_run = m_new;
-      // rescale by the factor of the running maximum, unconditionally (a branch around it makes the compiler keep two copies
-      // of the accumulators and move 64 registers per tile) and HERE, in segment A: B (exponentials + PV) is the longer one
+      // LAZY reference: m_run is the exponent reference of the row, not its exact running maximum.  It follows the maximum
+      // only when some row of the wave has outgrown it by more than 2^8 (always on a row's first visible tile: -inf + 8 =
+      // -inf); until then the probabilities are 2^(s - m_run) <= 2^8 - exact in fp32 and of the same relative precision in
+      // bf16 - and the accumulators need no rescale: 33 v_pk_mul_f32 per wave and tile (10 % of the tile's VALU issue)
+      // behind a wave-uniform branch that is taken a handful of times per call.  (m, l, O) stay consistent: the merge of the
+      // key halves and the split-KV combine use m_run as the partial's reference.
+      need = __any(m_new > m_run + 8.0f);
+      if (need) {
+        const float m_u = m_new == -INFINITY ? 0.f : m_new;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_u);     // exact rescale of every row of the wave to its own maximum
 #pragma unroll
-      for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
-      l_run *= alpha;
+        for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+      }
+      m_use = m_run == -INFINITY ? 0.f : m_run;
     };
     auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
       float rsum = 0.f;
