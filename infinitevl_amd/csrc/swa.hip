@@ -45,6 +45,14 @@ struct SwaParams {
   const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
 };
 
+// x mod C for a token position x >= 0 and a ring capacity C > 0: every workgroup computes the ring slot of its first key
+// from the device-resident position before it can request a tile, and a 64-bit remainder by a run-time divisor is ~150
+// instructions; positions below 2^32 (4 G tokens: the usual case, wave-uniform branch) take the 32-bit expansion.
+__device__ __forceinline__ int mod_pos(long long x, int C) {
+  if ((unsigned long long)x < 0x100000000ull) return (int)((unsigned int)x % (unsigned int)C);
+  return (int)(x % C);
+}
+
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
   mfma_bf16x8 r;
   __builtin_memcpy(&r, &v, 16);
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
   const int n_extra = p.T_new - p.T;
   const int n_prev = n_ring + n_extra;
   const int S = n_prev + p.T;
-  const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;     // ring slot of call-local key 0
+  const int s0 = p.C > 0 ? mod_pos(pos - n_ring, p.C) : 0;      // ring slot of call-local key 0
 
   // ---- rows of this workgroup / wave / lane ----------------------------------------------------
   const int total_rows = PACK ? p.T * G : p.T;
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
   const int n_prev = n_ring + (p.T_new - p.T);
   const int S = n_prev + p.T;
-  const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;
+  const int s0 = p.C > 0 ? mod_pos(pos - n_ring, p.C) : 0;
 
   const int tile_row0 = bx * PF_QT;
   // workgroup key-tile range
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
   const int n_extra = p.T_new - p.T;
   const int n_prev = n_ring + n_extra;
   const int S = n_prev + p.T;
-  const int s0 = p.C > 0 ? (int)((pos - n_ring) % p.C) : 0;
+  const int s0 = p.C > 0 ? mod_pos(pos - n_ring, p.C) : 0;
 
   const int total_rows = p.T * G;
   const int row = wave * 16 + l15;
@@ -1233,12 +1241,13 @@ __device__ __forceinline__ void ring_append(const AppendArgs& a, long long block
   const int t_first = a.T > a.C ? a.T - a.C : 0;
   const int nt = a.T - t_first;
   const long long total = (long long)a.B * nt * a.Hkv * (SWA_D / 8);
+  const int pos_slot = mod_pos(pos, a.C);
   for (long long idx = block * blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
     const int ch = (int)(idx % (SWA_D / 8));
     const int hk = (int)((idx / (SWA_D / 8)) % a.Hkv);
     const int tt = (int)((idx / ((long long)(SWA_D / 8) * a.Hkv)) % nt) + t_first;
     const int b = (int)(idx / ((long long)(SWA_D / 8) * a.Hkv * nt));
-    const int slot = (int)((pos + tt) % a.C);
+    const int slot = (int)(((unsigned int)pos_slot + (unsigned int)tt) % (unsigned int)a.C);      // (pos + tt) % C; pos_slot, tt < 2^31
     const long long src = (long long)b * a.kn_sb + (long long)tt * a.kn_st + (long long)hk * a.kn_sh + ch * 8;
     const long long dst = (((long long)b * a.Hkv + hk) * a.C + slot) * SWA_D + ch * 8;
     u32x4 kv = *(const u32x4*)(a.k_new + src);
