@@ -53,6 +53,18 @@ __device__ __forceinline__ int mod_pos(long long x, int C) {
   return (int)(x % C);
 }
 
+// x / d and x % d for an index x >= 0 and a divisor d > 0: 32-bit expansion while x < 2^32 (the index arithmetic of the
+// element-wise kernels around the attention is otherwise two or three 64-bit divisions per thread and iteration)
+__device__ __forceinline__ long long divmod_idx(long long x, int d, int& rem) {
+  if ((unsigned long long)x < 0x100000000ull) {
+    const unsigned int xx = (unsigned int)x, q = xx / (unsigned int)d;
+    rem = (int)(xx - q * (unsigned int)d);
+    return (long long)q;
+  }
+  rem = (int)(x % d);
+  return x / d;
+}
+
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
   mfma_bf16x8 r;
   __builtin_memcpy(&r, &v, 16);
@@ -1211,9 +1223,9 @@ __global__ __launch_bounds__(256) void swa_rope_prepass_kernel(const bf16_t* __r
   const long long plane = (long long)B * T * SWA_D;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(idx & 7);
-    const int h = (int)((idx >> 3) % HT);
-    const long long bt = (idx >> 3) / HT;
-    const int b = (int)(bt / T), t = (int)(bt % T);
+    int h, t;
+    const long long bt = divmod_idx(idx >> 3, HT, h);
+    const int b = (int)divmod_idx(bt, T, t);
     const bool is_q = h < Hq;
     const bf16_t* src = is_q ? q + (long long)b * q_sb + (long long)t * q_st + (long long)h * q_sh
                              : k + (long long)b * k_sb + (long long)t * k_st + (long long)(h - Hq) * k_sh;
@@ -1243,10 +1255,11 @@ __device__ __forceinline__ void ring_append(const AppendArgs& a, long long block
   const long long total = (long long)a.B * nt * a.Hkv * (SWA_D / 8);
   const int pos_slot = mod_pos(pos, a.C);
   for (long long idx = block * blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
-    const int ch = (int)(idx % (SWA_D / 8));
-    const int hk = (int)((idx / (SWA_D / 8)) % a.Hkv);
-    const int tt = (int)((idx / ((long long)(SWA_D / 8) * a.Hkv)) % nt) + t_first;
-    const int b = (int)(idx / ((long long)(SWA_D / 8) * a.Hkv * nt));
+    const int ch = (int)(idx & (SWA_D / 8 - 1));
+    int hk, tt;
+    const long long bt = divmod_idx(idx >> 4, a.Hkv, hk);          // SWA_D / 8 = 16 pieces per row
+    const int b = (int)divmod_idx(bt, nt, tt);
+    tt += t_first;
     const int slot = (int)(((unsigned int)pos_slot + (unsigned int)tt) % (unsigned int)a.C);      // (pos + tt) % C; pos_slot, tt < 2^31
     const long long src = (long long)b * a.kn_sb + (long long)tt * a.kn_st + (long long)hk * a.kn_sh + ch * 8;
     const long long dst = (((long long)b * a.Hkv + hk) * a.C + slot) * SWA_D + ch * 8;
@@ -1279,7 +1292,8 @@ __global__ __launch_bounds__(256) void swa_combine_kernel(const float* __restric
   const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nw = ((long long)ncb * blockDim.x) >> 6;
   for (long long r = wid; r < (long long)B * rows_per_b; r += nw) {
-    const long long b = r / rows_per_b, rr = r % rows_per_b;
+    int rr_;
+    const long long b = divmod_idx(r, rows_per_b, rr_), rr = rr_;
     float ms[NS], ls[NS];
     float2 ov[NS];
 #pragma unroll
@@ -1328,7 +1342,8 @@ __global__ __launch_bounds__(256) void swa_combine_wide_kernel(const float* __re
   const int ncb = ap.first_block >= 0 ? ap.first_block : (int)gridDim.x;       // combine blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long r = blockIdx.x; r < (long long)B * rows_per_b; r += ncb) {
-    const long long b = r / rows_per_b, rr = r % rows_per_b;
+    int rr_;
+    const long long b = divmod_idx(r, rows_per_b, rr_), rr = rr_;
     const bool on = lane < nsplit;
     const float2 ml = *(const float2*)(part_ml + ((b * nsplit + (on ? lane : 0)) * rows_per_b + rr) * 2);
     float2 ov[16];
