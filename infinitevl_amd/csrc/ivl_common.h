@@ -61,6 +61,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // here (the results are rounded to bf16 right after), so all paths stay bit-identical to each other
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// x / d and x % d for an index x >= 0 and a divisor d > 0: 32-bit expansion while x < 2^32 (the index arithmetic of the
+// element-wise kernels around the attention is otherwise two or three 64-bit divisions per thread and iteration)
+__device__ __forceinline__ long long divmod_idx(long long x, int d, int& rem) {
+  if ((unsigned long long)x < 0x100000000ull) {
+    const unsigned int xx = (unsigned int)x, q = xx / (unsigned int)d;
+    rem = (int)(xx - q * (unsigned int)d);
+    return (long long)q;
+  }
+  rem = (int)(x % d);
+  return x / d;
+}
+
 // ---- in-kernel timeline: DEVELOPER build only (`make trace` -> libivl_hip_trace.so, -DIVL_TRACE) ----------
 // The product library contains neither the clock reads nor the setter: every macro below compiles to nothing.
 // In the trace build a kernel keeps shader-clock readings in registers (IVL_T(name) declares/reads one) and

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_strided_kernel(
   float wf[8];
   unpack8(*(const u32x4*)(weight + lane32 * 8), wf);
   for (long long r = row0; r < rows; r += stride) {
-    const long long tok = r / H;
-    const int h = (int)(r % H);
+    int h;
+    const long long tok = divmod_idx(r, H, h);
     float xf[8], gf[8], o8[8];
     unpack8(*(const u32x4*)(x + r * 256 + lane32 * 8), xf);
     unpack8(*(const u32x4*)(gate + tok * gate_ld + h * 256 + lane32 * 8), gf);
@@ -236,6 +236,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(
   const int nvec = N / 8;
   float hv[4][8];
   float ss = 0.f;
+  // the weight vectors are requested with the row (behind the barrier they were a second memory round trip per launch,
+  // and the decoder step issues this kernel 72 times)
+  u32x4 wraw[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = tid + it * 256;
+    if (v < nvec) wraw[it] = *(const u32x4*)(weight + v * 8);
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int v = tid + it * 256;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(
     const int v = tid + it * 256;
     if (v < nvec) {
       float wv[8], o8[8];
-      unpack8(*(const u32x4*)(weight + v * 8), wv);
+      unpack8(wraw[it], wv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o8[i] = wv[i] * bf_round(hv[it][i] * rstd);
       *(u32x4*)(y + row * N + v * 8) = pack8(o8);
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
   const long long total = rows * nvec;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const long long r = idx / nvec;
-    const int v = (int)(idx % nvec);
+    int v;
+    const long long r = divmod_idx(idx, nvec, v);
     float a[8], b[8], o[8];
     unpack8(*(const u32x4*)(gu + r * 2 * I + v * 8), a);
     unpack8(*(const u32x4*)(gu + r * 2 * I + I + v * 8), b);

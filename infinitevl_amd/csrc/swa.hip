@@ -53,18 +53,6 @@ __device__ __forceinline__ int mod_pos(long long x, int C) {
   return (int)(x % C);
 }
 
-// x / d and x % d for an index x >= 0 and a divisor d > 0: 32-bit expansion while x < 2^32 (the index arithmetic of the
-// element-wise kernels around the attention is otherwise two or three 64-bit divisions per thread and iteration)
-__device__ __forceinline__ long long divmod_idx(long long x, int d, int& rem) {
-  if ((unsigned long long)x < 0x100000000ull) {
-    const unsigned int xx = (unsigned int)x, q = xx / (unsigned int)d;
-    rem = (int)(xx - q * (unsigned int)d);
-    return (long long)q;
-  }
-  rem = (int)(x % d);
-  return x / d;
-}
-
 __device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
   mfma_bf16x8 r;
   __builtin_memcpy(&r, &v, 16);
