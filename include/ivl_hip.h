@@ -30,14 +30,13 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 4
+#define IVL_ABI_VERSION 5
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
 
 /* element type codes for the arguments that accept more than one */
 #define IVL_BF16 0
-#define IVL_F16 1
 #define IVL_F32 2
 #define IVL_FP8_E4M3 3   /* OCP e4m3fn (gfx950); accepted only as `mma_dtype`: operand format of the MFMA products */
 
@@ -202,10 +201,9 @@ IVL_API int ivl_swa_cache_append(const void* k_new, const void* v_new, int64_t k
 /* 3-D rotary tables cos / sin bf16 [rows, 2*half_dim] from position ids (int64 [rows], rows = 3*B*T in (axis, batch,
  * token) order) and the inverse frequencies fp32 [half_dim]: cos(pos * inv_freq) in fp32, the frequencies repeated over
  * both halves of the channels, times attention_scaling, rounded to bf16.
- * Replaces InfiniteVLRotaryEmbedding.forward (std:896-930: cast, K=1 matmul, cat, cos, sin, scaling, cast) with one launch.
- * `advance` is reserved (pass 0). */
+ * Replaces InfiniteVLRotaryEmbedding.forward (std:896-930: cast, K=1 matmul, cat, cos, sin, scaling, cast) with one launch. */
 IVL_API int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int rows,
-                        int half_dim, float attention_scaling, int64_t advance, void* stream);
+                        int half_dim, float attention_scaling, void* stream);
 
 /* Vision-tower window attention: NON-causal softmax attention inside each segment
  * [cu_seqlens[s], cu_seqlens[s+1]) of one packed patch sequence, with the vision rotary embedding folded into the Q / K

@@ -13,13 +13,14 @@ Layout
 from . import _lib
 from .cache import StaticCachePrealloc, StaticLinearLayerPrealloc, StaticSlidingWindowLayerPrealloc
 from .modules import GatedDeltaNet, InfiniteVLRotaryEmbedding, InfiniteVLSelfAttention
-from .ops import (FusedRMSNormGated, ShortConvolution, apply_mrope_inplace, chunk_gated_delta_rule,
-                  fused_recurrent_gated_delta_rule, gdn_gate, swa_attention_interface, swa_forward)
+from .ops import (FusedRMSNormGated, RMSNorm, ShortConvolution, apply_mrope_inplace, chunk_gated_delta_rule,
+                  fused_recurrent_gated_delta_rule, gdn_gate, get_unpad_data, index_first_axis, pad_input,
+                  swa_attention_interface, swa_forward)
 
 __all__ = [
     "StaticCachePrealloc", "StaticLinearLayerPrealloc", "StaticSlidingWindowLayerPrealloc",
     "GatedDeltaNet", "InfiniteVLSelfAttention", "InfiniteVLRotaryEmbedding",
-    "FusedRMSNormGated", "ShortConvolution", "chunk_gated_delta_rule", "fused_recurrent_gated_delta_rule",
+    "FusedRMSNormGated", "RMSNorm", "ShortConvolution", "get_unpad_data", "index_first_axis", "pad_input", "chunk_gated_delta_rule", "fused_recurrent_gated_delta_rule",
     "gdn_gate", "apply_mrope_inplace", "swa_attention_interface", "swa_forward", "load_library",
 ]
 

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 
-IVL_BF16, IVL_F16, IVL_F32, IVL_FP8_E4M3 = 0, 1, 2, 3
+IVL_BF16, IVL_F32, IVL_FP8_E4M3 = 0, 2, 3
 IVL_OK = 0
 IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
 
@@ -82,7 +82,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_chunk_fused_fwd.argtypes = ([vp, c_int64, i, i, i, i, i] + [vp] * 9 + [vp, vp, vp, vp, i, vp, i] +
                                             [i, i, i, i, i, i, f, i, vp, sz, vp])
     lib.ivl_rope_tables_fwd.restype = i
-    lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, c_int64, vp]
+    lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, vp]
     lib.ivl_vision_attn_workspace_bytes.restype = sz
     lib.ivl_vision_attn_workspace_bytes.argtypes = [i, i, i, i]
     lib.ivl_vision_attn_fwd.restype = i

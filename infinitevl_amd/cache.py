@@ -218,6 +218,9 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
             new._buf_keys = self._buf_keys.clone()
             new._buf_values = self._buf_values.clone()
         new._pos_dev = self._pos_dev.clone()
+        # the clone's counter is private until an aggregate re-shares it (StaticCachePrealloc.clone does): a layer
+        # cloned or driven on its own must advance it itself, or ring slots and band drift from the host counters
+        new._advances_counter = True
         return new
 
     def copy_from(self, other: "StaticSlidingWindowLayerPrealloc") -> None:

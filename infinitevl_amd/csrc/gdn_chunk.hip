@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
         history_load(sk4, pf.st_in[1], 1);
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoidf_(bf2f(bin[rr])));          // beta = bf16(sigmoid(b)) (std:1293)
+      for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));          // beta = bf16(sigmoid(b)) (std:1293)
       IVL_T(tf0);
       IVL_TOUT(8, tf0 - tp0);
       if (own_state && r0 == 0) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const float av = p1_g + p1_dt;
       const float sp = av > 20.f ? av : log1pf(expf(av));
       g_ld = -expf(p1_A) * sp;
-      b_ld = bf2f(f2bf(sigmoidf_(p1_b)));
+      b_ld = bf2f(f2bf(sigmoid_exact_(p1_b)));
     } else {
       g_ld = p1_g;
       b_ld = p1_b;

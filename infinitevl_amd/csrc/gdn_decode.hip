@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * DNW) void gdn_decode_step_kernel(DecParams p) 
     const float sp = av > 20.f ? av : log1pf(expf(av));
     const float g = -expf(p.A_log[h]) * sp;
     s_sc[0] = __expf(g);
-    s_sc[1] = bf_round(sigmoidf_(bv));
+    s_sc[1] = bf_round(sigmoid_exact_(bv));
   }
   __syncthreads();
   if (tid < 2 * DK) {

@@ -60,6 +60,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // v_rcp_f32 (1 ulp) instead of an IEEE division (~10 instructions): every SiLU / swish gate of the package goes through
 // here (the results are rounded to bf16 right after), so all paths stay bit-identical to each other
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// beta = sigmoid(b) (std:1293) keeps the IEEE division and expf: it is H values per token, and a 1-ulp fp32 difference can
+// flip the bf16 rounding against the reference's `b.sigmoid()`
+__device__ __forceinline__ float sigmoid_exact_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // x / d and x % d for an index x >= 0 and a divisor d > 0: 32-bit expansion while x < 2^32 (the index arithmetic of the
 // element-wise kernels around the attention is otherwise two or three 64-bit divisions per thread and iteration)

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gdn_prologue_kernel(ProParams p) {
       const float bv = bf2f(p.proj[row * p.ld + p.col_b + h]);
       const float sp = av > 20.f ? av : log1pf(expf(av));
       p.g[i] = -expf(p.A_log[h]) * sp;
-      p.beta[i] = f2bf(sigmoidf_(bv));
+      p.beta[i] = f2bf(sigmoid_exact_(bv));
     }
     return;
   }

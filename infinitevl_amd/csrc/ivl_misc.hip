@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gdn_gate_kernel(
     const float av = bf2f(a[i]) + dt_bias[h];
     const float sp = av > 20.f ? av : log1pf(expf(av));
     g[i] = -expf(A_log[h]) * sp;
-    beta[i] = f2bf(sigmoidf_(bf2f(b[i])));
+    beta[i] = f2bf(sigmoid_exact_(bf2f(b[i])));
   }
 }
 
@@ -346,7 +346,7 @@ extern "C" int ivl_mrope_fwd(void* q, void* k, const void* cos, const void* sin,
 }
 
 extern "C" int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int rows,
-                                   int half_dim, float attention_scaling, int64_t advance, void* stream) {
+                                   int half_dim, float attention_scaling, void* stream) {
   IVL_REQUIRE(position_ids && inv_freq && cos_out && sin_out, IVL_ERR_INVALID_ARG, "ivl_rope_tables_fwd: NULL pointer");
   IVL_REQUIRE(rows > 0 && half_dim > 0 && half_dim % 2 == 0, IVL_ERR_INVALID_ARG, "ivl_rope_tables_fwd: bad sizes rows=%d half_dim=%d",
               rows, half_dim);
@@ -355,9 +355,7 @@ extern "C" int ivl_rope_tables_fwd(const int64_t* position_ids, const float* inv
   if (gb > 1024) gb = 1024;
   hipLaunchKernelGGL(rope_tables_kernel, dim3((int)gb), dim3(256), 0, (hipStream_t)stream, (const long long*)position_ids, inv_freq,
                      (bf16_t*)cos_out, (bf16_t*)sin_out, rows, half_dim, attention_scaling);
-  int rc = check_launch("ivl_rope_tables_fwd");
-  (void)advance;
-  return rc;
+  return check_launch("ivl_rope_tables_fwd");
 }
 
 extern "C" int ivl_counter_add(int64_t* counter, int64_t delta, void* stream) {

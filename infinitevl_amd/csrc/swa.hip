@@ -1469,7 +1469,10 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (prefill && nsplit > 1 && p.rcos != nullptr) {
     // rotate q and the call's keys once, into the workspace behind the partials (see swa_rope_prepass_kernel)
-    const size_t n_part = ((size_t)a->B * nsplit * a->T * a->Hq * (SWA_D + 2)) * sizeof(float);
+    // rounded up to 16 bytes: the pre-pass, the attention kernel and the ring append move q_rot / k_rot as 16-byte vectors
+    // (B * nsplit * T * Hq * 130 floats is only 8-byte aligned for an odd row count; the +256 slack of
+    // ivl_swa_workspace_bytes covers the padding)
+    const size_t n_part = (((size_t)a->B * nsplit * a->T * a->Hq * (SWA_D + 2)) * sizeof(float) + 15) & ~(size_t)15;
     const size_t n_q = (size_t)a->B * a->T * a->Hq * SWA_D, n_k = (size_t)a->B * a->T * a->Hkv * SWA_D;
     IVL_REQUIRE(a->workspace_bytes >= n_part + (n_q + n_k) * sizeof(bf16_t), IVL_ERR_WORKSPACE,
                 "ivl_swa_fwd: workspace %zu bytes < required %zu (rope pre-pass)", a->workspace_bytes, n_part + (n_q + n_k) * sizeof(bf16_t));

@@ -176,8 +176,6 @@ class GatedDeltaNet(nn.Module):
         assert self.mode in ["chunk", "fused_recurrent"], f"Not suppoerted mode `{self.mode}`."
         if not self.use_short_conv:
             raise UserWarning("ShortConvolution is crucial to the performance. Do not turn it off.")
-        if not self.use_gate:
-            raise NotImplementedError("InfiniteVL ships use_gate=True (configuration_infinitevl.py)")
         if self.num_key_value_heads != self.num_heads:
             raise NotImplementedError(
                 f"num_linear_key_value_heads ({self.num_key_value_heads}) != num_linear_heads ({self.num_heads}): the "
@@ -199,8 +197,11 @@ class GatedDeltaNet(nn.Module):
         self.q_conv1d = ops.ShortConvolution(self.num_heads * self.head_dim, self.conv_size, activation="silu")
         self.k_conv1d = ops.ShortConvolution(self.key_dim, self.conv_size, activation="silu")
         self.v_conv1d = ops.ShortConvolution(self.value_dim, self.conv_size, activation="silu")
-        self.g_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_v_dim, bias=False)
-        self.o_norm = ops.FusedRMSNormGated(self.head_v_dim, eps=self.norm_eps)
+        if self.use_gate:                                                              # std:1209-1213
+            self.g_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_v_dim, bias=False)
+            self.o_norm = ops.FusedRMSNormGated(self.head_v_dim, eps=self.norm_eps)
+        else:
+            self.o_norm = ops.RMSNorm(self.head_v_dim, eps=self.norm_eps)
         self.o_proj = nn.Linear(self.num_heads * self.head_v_dim, self.hidden_size, bias=False)
         self._fused_w = None
         self._fused_cols = None
@@ -212,6 +213,8 @@ class GatedDeltaNet(nn.Module):
         """Inference-time: q|k|v|g|a|b projection weights in ONE tensor (one GEMM instead of six; rows padded
         to a multiple of 8) with the original parameters re-pointed at views of it (names/shapes/state_dict
         unchanged, no duplicated memory), plus fp32 copies of A_log / dt_bias for the gate math."""
+        if not self.use_gate:                        # the fused path reads its gate from the projection buffer
+            return self
         ws = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.g_proj.weight,
               self.a_proj.weight, self.b_proj.weight]
         total = sum(w.shape[0] for w in ws)
@@ -341,8 +344,11 @@ class GatedDeltaNet(nn.Module):
                 recurrent_state=next_state,
                 cache_kwargs={"op": "set", "delta_len": q_len, "cache_position": cache_position})
 
-        g_gate = self.g_proj(hidden_states).view(batch_size, q_len, self.num_heads, self.head_v_dim)
-        o = self.o_norm(o, g_gate)                                                     # std:1336-1338
+        if self.use_gate:                                                              # std:1336-1341
+            g_gate = self.g_proj(hidden_states).view(batch_size, q_len, self.num_heads, self.head_v_dim)
+            o = self.o_norm(o, g_gate)
+        else:
+            o = self.o_norm(o)
         o = self.o_proj(o.reshape(batch_size, q_len, -1))
         return o, None
 
@@ -380,6 +386,13 @@ class InfiniteVLVisionAttention(nn.Module):
         if max_seqlen is None:
             win = kwargs.get("win_lengths_list", None)                      # the streaming variant's precomputed list (strm:773)
             max_seqlen = max(win) if win else int((cu_seqlens[1:] - cu_seqlens[:-1]).max())
+        if position_embeddings is None:
+            # older call sites hand over the raw frequencies only (HF Qwen2.5-VL: emb = cat(freqs, freqs) -> cos / sin);
+            # with neither the reference fails on unpacking None (strm:742) - so do we, with a message
+            if rotary_pos_emb is None:
+                raise TypeError("InfiniteVLVisionAttention.forward needs position_embeddings=(cos, sin) or rotary_pos_emb")
+            emb = torch.cat((rotary_pos_emb, rotary_pos_emb), dim=-1).float()
+            position_embeddings = (emb.cos(), emb.sin())
         attn = ops.vision_window_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, int(max_seqlen), self.scaling,
                                            rope=position_embeddings)
         return self.proj(attn.view(seq_length, -1))

@@ -3,7 +3,8 @@ third-party operators the reference calls (SURVEY.md section 8b "Operator-level 
 the gfx950 kernels of libivl_hip.so.  PyTorch is used for device memory and streams only.
 
     chunk_gated_delta_rule / fused_recurrent_gated_delta_rule   <- fla.ops.gated_delta_rule  (std:1297-1320)
-    ShortConvolution, FusedRMSNormGated                         <- fla.modules               (std:1187-1210)
+    ShortConvolution, FusedRMSNormGated, RMSNorm                <- fla.modules               (std:53, 1187-1213)
+    get_unpad_data, index_first_axis, pad_input                 <- fla.layers.utils          (std:52, 1253-1258, 1344-1345)
     swa_attention_interface                                     <- ALL_ATTENTION_FUNCTIONS["flash_attention_2"] (std:1097-1108)
     gdn_gate, apply_mrope_inplace                               <- torch glue at std:1293-1294 / std:1057-1064
 
@@ -76,7 +77,9 @@ def get_workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch
         if ws is not None and _GRAPH_PINNED.get(key):
             _RETIRED.append(ws)
             _GRAPH_PINNED[key] = False
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        # geometric growth bounds the number of retired (graph-pinned) buffers of a run whose calls keep growing
+        grown = 2 * ws.numel() if ws is not None else 0
+        ws = torch.empty(max(int(nbytes), grown, 1 << 20), dtype=torch.uint8, device=device)
         _WORKSPACES[key] = ws
     if capturing:
         _GRAPH_PINNED[key] = True
@@ -226,8 +229,12 @@ def rope_tables(position_ids: torch.Tensor, inv_freq: torch.Tensor, attention_sc
     cos = torch.empty(*pos.shape, 2 * half, dtype=torch.bfloat16, device=pos.device)
     sin = torch.empty_like(cos)
     _lib.check(_lib.load().ivl_rope_tables_fwd(_p(pos), _p(inv_freq), _p(cos), _p(sin), pos.numel(), half,
-                                               float(attention_scaling), 0, _stream(pos)))
+                                               float(attention_scaling), _stream(pos)))
     return cos, sin
+
+
+# Host-side check of cu_seqlens / max_seqlen in vision_window_attention (one device sync per eager call; never under capture).
+_VALIDATE_VISION_SEGMENTS = False
 
 
 def vision_window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
@@ -250,7 +257,14 @@ def vision_window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, c
     if rope is not None:
         cos, sin = (x if x.dtype == torch.float32 and x.is_contiguous() else x.float().contiguous() for x in rope)
         assert tuple(cos.shape) == (S, d) and tuple(sin.shape) == (S, d), "vision rotary tables are [S, head_dim]"
-    o = torch.empty(S, H, d, dtype=torch.bfloat16, device=q.device)
+    # tokens outside every segment (cu_seqlens[-1] < S) and tiles beyond an under-estimated max_seqlen are skipped by the
+    # kernel: they read as zeros, never as uninitialised memory; outside a graph capture the bound itself is checked
+    o = torch.zeros(S, H, d, dtype=torch.bfloat16, device=q.device)
+    if not torch.cuda.is_current_stream_capturing() and _VALIDATE_VISION_SEGMENTS:
+        lens = cu[1:] - cu[:-1]
+        if int(cu[-1]) != S or (lens.numel() and int(lens.max()) > int(max_seqlen)):
+            raise ValueError(f"vision_window_attention: cu_seqlens must cover all {S} tokens (ends at {int(cu[-1])}) and "
+                             f"max_seqlen={int(max_seqlen)} must bound the segment lengths (max {int(lens.max())})")
     lib = _lib.load()
     ws_bytes = lib.ivl_vision_attn_workspace_bytes(S, H, d, int(max_seqlen)) if cos is not None else 0
     ws = get_workspace(ws_bytes, q.device, "vision") if ws_bytes else None
@@ -363,6 +377,54 @@ class FusedRMSNormGated(nn.Module):
         _lib.check(_lib.load().ivl_rmsnorm_swish_gate_fwd(_p(x), _p(g), _p(w.contiguous()), _p(y),
                                                           x.numel() // N, N, float(self.eps), _stream(x)))
         return y
+
+
+class RMSNorm(nn.Module):
+    """y = rmsnorm(x) * weight over the last dim (fla.modules.RMSNorm; the reference's `o_norm` when
+    `use_gate=False`, std:1213 / std:1341).  Same constructor and parameter names as fla's; the arithmetic is the
+    residual-free form of ivl_add_rmsnorm_fwd (fp32 statistics, bf16 in / out)."""
+
+    def __init__(self, hidden_size: int, elementwise_affine: bool = True, bias: bool = False, eps: float = 1e-5,
+                 device=None, dtype=None):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("InfiniteVL's norms carry no bias")
+        self.hidden_size, self.elementwise_affine, self.eps = hidden_size, elementwise_affine, eps
+        self.register_parameter("weight", None)
+        self.register_parameter("bias", None)
+        if elementwise_affine:
+            self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+
+    def extra_repr(self) -> str:
+        return f"{self.hidden_size}, eps={self.eps}" + ("" if self.elementwise_affine else ", elementwise_affine=False")
+
+    def forward(self, x: torch.Tensor, residual=None, prenorm: bool = False, residual_in_fp32: bool = False):
+        if residual is not None or prenorm:
+            raise NotImplementedError("residual/prenorm are not used by InfiniteVL (std:1341)")
+        w = self.weight if self.weight is not None else torch.ones(self.hidden_size, dtype=x.dtype, device=x.device)
+        y, _ = add_rmsnorm(x, None, w, self.eps)
+        return y
+
+
+def get_unpad_data(attention_mask: torch.Tensor):
+    """(indices, cu_seqlens, max_seqlen_in_batch) of a 0/1 padding mask [B, S] (fla.layers.utils; std:1254).  The GDN
+    mixer nulls its mask (std:1223), so nothing on the hot path reaches this; kept so that `std:52` is a pure rename."""
+    lens = attention_mask.sum(dim=-1, dtype=torch.int32)
+    indices = torch.nonzero(attention_mask.flatten(), as_tuple=False).flatten()
+    cu = torch.nn.functional.pad(torch.cumsum(lens, dim=0, dtype=torch.int32), (1, 0))
+    return indices, cu, int(lens.max().item()) if lens.numel() else 0
+
+
+def index_first_axis(x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+    """Rows `indices` of x [(b s), ...] (fla.layers.utils; std:1255-1258)."""
+    return x.index_select(0, indices)
+
+
+def pad_input(x: torch.Tensor, indices: torch.Tensor, batch: int, seqlen: int) -> torch.Tensor:
+    """Inverse of index_first_axis: x [total, ...] scattered into zeros [batch, seqlen, ...] (std:1345)."""
+    out = torch.zeros(batch * seqlen, *x.shape[1:], dtype=x.dtype, device=x.device)
+    out.index_copy_(0, indices, x)
+    return out.view(batch, seqlen, *x.shape[1:])
 
 
 # ---------------------------------------------------------------------------------------------

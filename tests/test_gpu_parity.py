@@ -1115,6 +1115,117 @@ def test_swa_module_with_reference_style_cat_cache_equals_ring_cache(fuse):
     assert torch.equal(ring.layers[0].keys, cat.k)          # same tokens kept, same order, bit for bit
 
 
+class _RefLinearCache:
+    """A linear-attention cache that follows the REFERENCE protocol (std:286-340) without being our class: the first call
+    returns ((None, None, None), None) whatever it holds (`start`, std:298-300); "get" hands out the pre-allocated
+    cache-dtype tensors; "set" `.copy_`-downcasts what the operators RETURNED (new conv-state tensors, an fp32
+    `final_state`) into them (std:314-335) and advances `seq_len`.  Drives the `native=False` branch of
+    modules.GatedDeltaNet.forward: operators return fresh tensors, the cache does the bf16 rounding."""
+
+    class _Layer:
+        def __init__(self, B, H, K, V, Dq, Dk, Dv, W, dtype):
+            mk = lambda *s: torch.full(s, float("nan"), dtype=dtype, device=DEV)  # noqa: E731   (torch.empty: std:277-284)
+            self.conv_state_q, self.conv_state_k, self.conv_state_v = mk(B, Dq, W), mk(B, Dk, W), mk(B, Dv, W)
+            self.recurrent_state = mk(B, H, K, V)
+            self.start, self.seq_len = False, 0
+
+    def __init__(self, n_layers, gdn, B, dtype=torch.bfloat16):
+        H, K, V = gdn.num_heads, gdn.head_k_dim, gdn.head_v_dim
+        self.layers = [self._Layer(B, H, K, V, H * K, gdn.key_dim, gdn.value_dim, gdn.conv_size, dtype) for _ in range(n_layers)]
+        self.seen_fp32_state = False
+
+    def update(self, layer_idx, key_states=None, value_states=None, conv_state=None, recurrent_state=None, cache_kwargs=None):
+        L = self.layers[layer_idx]
+        op = (cache_kwargs or {}).get("op", "get" if (conv_state is None and recurrent_state is None) else "set")
+        if L.start is False:
+            L.start = True
+            return (None, None, None), None
+        if op == "get":
+            return (L.conv_state_q, L.conv_state_k, L.conv_state_v), L.recurrent_state
+        for dst, src in zip((L.conv_state_q, L.conv_state_k, L.conv_state_v), conv_state):
+            assert tuple(src.shape) == tuple(dst.shape)
+            dst.copy_(src)
+        assert tuple(recurrent_state.shape) == tuple(L.recurrent_state.shape)
+        self.seen_fp32_state |= recurrent_state.dtype == torch.float32           # chunk_delta_h.py:291: fp32 final_state
+        L.recurrent_state.copy_(recurrent_state)                                  # std:335: rounded to the cache dtype
+        L.seq_len += int(cache_kwargs.get("delta_len", 0))
+        return (L.conv_state_q, L.conv_state_k, L.conv_state_v), L.recurrent_state
+
+
+def test_gdn_module_with_reference_protocol_linear_cache_equals_native_cache():
+    """GatedDeltaNet (un-fused weights) against a foreign cache that speaks the reference's get / set protocol, beside our
+    own in-place cache: chunk calls, a 64 / 65-token mode boundary (std:1230), recurrent calls and single tokens.  The
+    operators return an fp32 final state and the cache rounds it with `.copy_` (std:325-335) where the native path has
+    the kernel write bf16 in place - the same rounding point, so states and outputs agree to bf16 rounding of identical
+    fp32 values (bit-equal states; outputs equal up to the kernels' own run-to-run determinism: bit-equal)."""
+    stack, hc, _, _ = _small_stack(window=96, fuse=False)
+    gdn = stack.layers[1].self_attn
+    native = stack.allocate_inference_cache(2)
+    ref = _RefLinearCache(len(stack.layers), gdn, 2)
+    with torch.no_grad():
+        for T in (130, 65, 64, 1, 1, 200, 7):
+            x = bf(torch.randn(2, T, hc.hidden_size) * 0.5).to(DEV)
+            o1, _ = gdn(x, past_key_values=native)
+            o2, _ = gdn(x, past_key_values=ref)
+            assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 1e-6, T
+            L1, L2 = native.layers[1], ref.layers[1]
+            assert torch.equal(L1.recurrent_state, L2.recurrent_state), T
+            for a, b in ((L1.conv_state_q, L2.conv_state_q), (L1.conv_state_k, L2.conv_state_k), (L1.conv_state_v, L2.conv_state_v)):
+                assert torch.equal(a, b), T
+    assert ref.seen_fp32_state and ref.layers[1].seq_len == native.layers[1].seq_len == 468
+
+
+def test_ops_exports_every_name_the_reference_imports_from_fla():
+    """std:52-54 imports eight names from fla; infinitevl_amd.ops provides all of them."""
+    from infinitevl_amd import ops
+    for name in ("get_unpad_data", "index_first_axis", "pad_input", "FusedRMSNormGated", "RMSNorm", "ShortConvolution",
+                 "chunk_gated_delta_rule", "fused_recurrent_gated_delta_rule"):
+        assert hasattr(ops, name), name
+    # RMSNorm = the use_gate=False output norm (std:1213 / 1341), on the HIP norm kernel
+    x = bf(torch.randn(3, 70, 4, 256)).to(DEV)
+    norm = ops.RMSNorm(256, eps=1e-5).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        norm.weight.copy_(bf(torch.randn(256)))
+        y = norm(x).float().cpu()
+    xf, wf = x.float().cpu(), norm.weight.float().cpu()
+    want = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * wf
+    assert rms_rel(y, want) < 4e-3
+    # unpad helpers: round trip through a padding mask (flash-attn bert_padding semantics)
+    mask = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 0]], device=DEV)
+    idx, cu, mx = ops.get_unpad_data(mask)
+    assert idx.tolist() == [0, 1, 2, 4, 5] and cu.tolist() == [0, 3, 5] and mx == 3 and cu.dtype == torch.int32
+    h = torch.arange(8 * 3, device=DEV, dtype=torch.float32).view(8, 3)
+    back = ops.pad_input(ops.index_first_axis(h, idx), idx, 2, 4)
+    assert torch.equal(back.view(8, 3)[idx], h[idx]) and float(back.view(8, 3)[3].abs().sum()) == 0.0
+
+
+def test_gdn_module_without_output_gate():
+    """use_gate=False (std:1209-1213, 1336-1341): no g_proj, plain RMSNorm on the mixer output."""
+    import copy as _copy
+    from infinitevl_amd.modules import GatedDeltaNet
+    stack, hc, _, _ = _small_stack(window=96, fuse=False)
+    cfg = _copy.copy(hc)
+    cfg.use_gate = False
+    torch.manual_seed(0)
+    m = GatedDeltaNet(cfg, 1).to(DEV, torch.bfloat16).eval()
+    assert not hasattr(m, "g_proj") and type(m.o_norm).__name__ == "RMSNorm"
+    g = stack.layers[1].self_attn
+    sd = {k: v for k, v in g.state_dict().items() if not k.startswith("g_proj")}
+    m.load_state_dict(sd)
+    x = bf(torch.randn(1, 130, hc.hidden_size) * 0.5).to(DEV)
+    with torch.no_grad():
+        o, _ = m(x)
+        # the same mixer core with the gate: undo gate and norm by recomputing from the core output is not possible from
+        # outside, so check the structure instead: finite, right shape, and equal to o_proj(rmsnorm(core)) rebuilt by hand
+        from infinitevl_amd import ops
+        q, _ = m.q_conv1d(m.q_proj(x)); k, _ = m.k_conv1d(m.k_proj(x)); v, _ = m.v_conv1d(m.v_proj(x))
+        gg, beta = ops.gdn_gate(m.a_proj(x), m.b_proj(x), m.A_log, m.dt_bias)
+        core, _ = ops.chunk_gated_delta_rule(q.view(1, 130, m.num_heads, -1), k.view(1, 130, m.num_heads, -1),
+                                             v.view(1, 130, m.num_heads, -1), gg, beta, use_qk_l2norm_in_kernel=True)
+        want = m.o_proj(m.o_norm(core).reshape(1, 130, -1))
+    assert o.shape == x.shape and torch.equal(o, want)
+
+
 def test_cache_error_behaviour_on_gpu():
     from infinitevl_amd.cache import StaticCachePrealloc
     stack, hc, _, _ = _small_stack(window=96)

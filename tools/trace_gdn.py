@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from infinitevl_amd import _lib, ops
-lib = _lib.load(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "infinitevl_amd", "libivl_hip_trace.so"))
+lib = _lib.load(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "tools", "libivl_hip_trace.so"))
 dev = torch.device("cuda", 0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 lib.ivl_debug_set_scan_waves(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

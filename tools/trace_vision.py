@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from infinitevl_amd import _lib, ops
-lib = _lib.load(os.path.join(ROOT, "infinitevl_amd", "libivl_hip_trace.so"))
+lib = _lib.load(os.path.join(ROOT, "tools", "libivl_hip_trace.so"))
 dev = torch.device("cuda", 0)
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 seg = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
