@@ -69,22 +69,25 @@ def parse():
     ap.add_argument("--layers", type=int, default=36, help="debug only; the reported config is 36")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg1", action="store_true", help="skip the 4K one-call prefill + decode leg (configs[1])")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the bulk-prefill leg (configs[3]: 4096-token calls at >= 128K context)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (e4m3) leg (BASELINE.json configs[4])")
     return ap.parse_args()
 
 
 def event_time_ms(fn, iters, stream):
-    """Average GPU duration of `fn`: `iters` calls are captured into one hipGraph (so the measurement is
-    not bound by the Python/ctypes launch overhead of ~10-30 us per call) and the replay is timed with HIP
-    events recorded on the stream the kernels run on."""
-    for _ in range(3):
-        fn()
+    """Average GPU duration of `fn(i)`: `iters` calls (i = 0 .. iters-1) are captured into one hipGraph (so the measurement
+    is not bound by the Python/ctypes launch overhead of ~10-30 us per call) and the replay is timed with HIP events
+    recorded on the stream the kernels run on.  `fn` picks its input set from i: the step-phase entries rotate over input
+    sets that together exceed the L2s, so a launch does not find the previous launch's lines there (in the real step the
+    inputs of a kernel were written by the GEMM in front of it, not read by its own previous launch)."""
+    for i in range(3):
+        fn(i)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fn(i)
     graph.replay()
     torch.cuda.synchronize()
     cur = torch.cuda.current_stream()
@@ -98,11 +101,93 @@ def event_time_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / (iters * reps)
 
 
-def kernel_timings(device, chunk, window, only=None):
-    """Per-launch GPU time of every hot-path kernel at the bench shapes (B=1, T=chunk, InfiniteVL-3B head
-    shapes, full window), plus two throughput-regime shapes (T=4096) for the two heavy kernels.  Each entry:
-    ms per launch, launches per prefill step, the roofline that bounds it, algorithmic bytes/flops per
-    launch and the achieved rate."""
+# rocprofv3 kernel-trace rows (kernel-name prefix, grid threads) that make up ONE call of an entry of `kernels`: used to
+# attach the committed in-step durations (profiles/rNN_bench_kernel_by_grid.csv) and PMC traffic (rNN_pmc_traffic.json)
+PROFILE_ROWS = {
+    "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
+    "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, true>", 32768),
+                                                  ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
+    "swa_prefill(rope pre-pass + attention + combine with append)": [("ivl::swa_rope_prepass_kernel", 36864),
+                                                                     ("ivl::swa_prefill_kernel", 196608),
+                                                                     ("ivl::swa_combine_kernel<8, true>", 270336)],
+    "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
+    "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
+    "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],
+    "silu_mul(SwiGLU gate)": [("ivl::silu_mul_kernel", 352256)],
+    "rope_tables": [("ivl::rope_tables_kernel", 49152)],
+    "counter_add": [("ivl::counter_add_kernel", 64)],
+    "gdn_recurrent(decode)": [("ivl::gdn_recurrent_kernel", 32768)],
+    "gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)": [("ivl::gdn_decode_step_kernel", 8192)],
+    "swa_decode": [("ivl::swa_fwd_kernel<true, 1>", 32768), ("ivl::swa_combine_wide_kernel", 4352)],
+    "add_rmsnorm(decode token)": [("ivl::add_rmsnorm_kernel", 256)],
+}
+
+
+def _newest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def in_step_us(kernel_name, chunk, window):
+    """Duration of one call of a `kernels` entry INSIDE the real step / decode token: the sum over its launches of the
+    (kernel, grid) averages of the newest committed rocprofv3 trace of this same command
+    (profiles/rNN_bench_kernel_by_grid.csv, tools/collect_profiles.sh).  None when the shapes differ from the profiled
+    ones or a row is missing (kernel renamed / regridded since the profile was taken)."""
+    import csv
+    want = PROFILE_ROWS.get(kernel_name)
+    path = _newest_profile("r*_bench_kernel_by_grid.csv")
+    if not want or path is None or chunk != 256 or window != 4096:
+        return None
+    rows = {(r["kernel"], int(r["grid_threads"])): float(r["avg_ns"]) for r in csv.DictReader(open(path))}
+    total = 0.0
+    for base, grid in want:
+        hit = [v for (n, g), v in rows.items() if g == grid and n.startswith(base)]
+        if len(hit) != 1:
+            return None
+        total += hit[0]
+    return {"us": total / 1e3, "source": os.path.basename(path)}
+
+
+def profile_replays(replay, n=4):
+    """Per-kernel GPU durations INSIDE a captured step, measured live: `n` replays of the hipGraph under torch.profiler (the
+    rocprofiler activity records of the replayed kernels).  Returns {kernel name without arguments: (avg_us, launches per
+    replay)}.  This is the in-process twin of tools/collect_profiles.sh's rocprofv3 --kernel-trace of the same command."""
+    import collections
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(n):
+            replay()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(list)
+    for ev in prof.events():
+        if "cuda" in str(ev.device_type).lower():
+            dur = ev.device_time if hasattr(ev, "device_time") else ev.cuda_time
+            agg[ev.name.split("(")[0].replace("void ", "").strip()].append(float(dur))
+    return {k: (sum(v) / len(v), len(v) / n) for k, v in agg.items()}
+
+
+def live_in_step_us(kernel_name, live):
+    """One call of a `kernels` entry inside the profiled graph: the sum of the live averages of its launches (PROFILE_ROWS)."""
+    want = PROFILE_ROWS.get(kernel_name)
+    if not want or not live:
+        return None
+    total = 0.0
+    for base, _grid in want:
+        hit = [v[0] for n, v in live.items() if n.startswith(base)]
+        if len(hit) != 1:
+            return None
+        total += hit[0]
+    return total
+
+
+def kernel_timings(device, chunk, window, only=None, live_prefill=None, live_decode=None):
+    """Per-call GPU time of every hot-path kernel at the bench shapes (B=1, T=chunk, InfiniteVL-3B head shapes, full
+    window), plus throughput-regime shapes (B=8, T=4096) for the two heavy kernels.  Each entry: `phase` ("prefill":
+    part of the streaming step, "decode": part of a decode token, "other": not in either), ms per call, calls per step /
+    token, the roofline that bounds it, algorithmic bytes / flops per call and the achieved rate.
+    Step- and token-phase entries are timed over rotating input sets (see event_time_ms)."""
     from infinitevl_amd import ops
     st = torch.cuda.current_stream(device)
     B, T, H, K, V, Hq, Hkv, d = 1, chunk, 16, 128, 256, 16, 2, 128
@@ -110,8 +195,9 @@ def kernel_timings(device, chunk, window, only=None):
     rn = lambda *s: torch.randn(*s, device=device, generator=g_).to(torch.bfloat16)  # noqa: E731
     C = window - 1
     res = {}
+    NS = 6                                         # input sets a step-phase entry rotates over
 
-    def add(name, fn, iters, per_step, bound, work):
+    def add(name, fn, iters, phase, per, bound, work):
         if only == "!large":                       # the PMC passes: bench-shape launches only (keyed by kernel + grid)
             if "@T=" in name or "@B=" in name:
                 return
@@ -119,112 +205,172 @@ def kernel_timings(device, chunk, window, only=None):
             return
         ms = event_time_ms(fn, iters, st)
         if bound == "hbm":
-            res[name] = dict(ms=ms, launches_per_step=per_step, bound="hbm", alg_bytes=work,
+            res[name] = dict(phase=phase, ms=ms, bound="hbm", alg_bytes=work,
                              achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         else:
-            res[name] = dict(ms=ms, launches_per_step=per_step, bound="mfma", alg_flops=work,
+            res[name] = dict(phase=phase, ms=ms, bound="mfma", alg_flops=work,
                              achieved=work / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+        res[name]["launches_per_step"] = per if phase == "prefill" else 0
+        res[name]["launches_per_decode_token"] = per if phase == "decode" else 0
         res[name]["frac"] = res[name]["achieved"] / res[name]["peak"]
+        # the same call inside the real step / decode token: measured live in this run (torch.profiler over replays of the
+        # captured graph) and, as a cross-check, from the committed rocprofv3 trace of this command
+        live = live_in_step_us(name, live_prefill if phase == "prefill" else live_decode if phase == "decode" else None)
+        ins = in_step_us(name, chunk, window)
+        if ins is not None:
+            res[name]["in_step_us_rocprofv3"] = ins["us"]
+            res[name]["in_step_rocprofv3_source"] = ins["source"]
+        if live is not None or ins is not None:
+            us = live if live is not None else ins["us"]
+            res[name]["in_step_us"] = us
+            res[name]["in_step_source"] = "live: torch.profiler over replays of the captured graph" if live is not None else ins["source"]
+            res[name]["frac_in_step"] = work / (us * 1e-6) / (1e9 if bound == "hbm" else 1e12) / res[name]["peak"]
 
-    def gdn_inputs(Tn):
-        q, k, v = rn(B, Tn, H, K), rn(B, Tn, H, K), rn(B, Tn, H, V)
-        beta = torch.rand(B, Tn, H, device=device, generator=g_).to(torch.bfloat16)
-        g = torch.nn.functional.logsigmoid(torch.randn(B, Tn, H, device=device, generator=g_))
+    def gdn_inputs(Tn, Bn=B):
+        q, k, v = rn(Bn, Tn, H, K), rn(Bn, Tn, H, K), rn(Bn, Tn, H, V)
+        beta = torch.rand(Bn, Tn, H, device=device, generator=g_).to(torch.bfloat16)
+        g = torch.nn.functional.logsigmoid(torch.randn(Bn, Tn, H, device=device, generator=g_))
         return q, k, v, g, beta
 
-    state = torch.randn(B, H, K, V, device=device, generator=g_).to(torch.bfloat16)
+    states = [torch.randn(B, H, K, V, device=device, generator=g_).to(torch.bfloat16) for _ in range(NS)]
+    state = states[0]
     # GDN bytes: 24,672 B/token/layer + state read+write per call in the dtype actually passed (bf16 cache: SURVEY.md Q5)
     sbytes = 2 * H * K * V * state.element_size()
-    q, k, v, g, beta = gdn_inputs(T)
-    add("gdn_chunk(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
-        q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        20, 0, "hbm", 24672.0 * T + sbytes)
-    add("gdn_chunk_fp8(prepare+scan)", lambda: ops.chunk_gated_delta_rule(
-        q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
-        20, 0, "hbm", 24672.0 * T + sbytes)
-    # SWA prefill: T queries over a full ring (W-1 cached keys) + T new keys; 8192*min(p+1,W) FLOP/token/layer
-    kc, vc = rn(B, Hkv, C, d), rn(B, Hkv, C, d)
-    pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
-    qs, kn, vn = rn(B, T, Hq, d), rn(B, T, Hkv, d), rn(B, T, Hkv, d)
-    add("swa_prefill", lambda: ops.swa_forward(qs, kn, vn, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
-                                               pos_dev=pos_dev), 20, 9, "mfma", 4.0 * Hq * d * window * T)
-    add("swa_cache_append", lambda: ops.swa_cache_append(kn, vn, kc, vc, pos_dev=pos_dev), 50, 9, "hbm",
-        4.0 * T * Hkv * d * 2)
-    # fused prologue (3 convs + gate math from one projection buffer), gated norm, decoder-layer norm
+    gin = [gdn_inputs(T) for _ in range(NS)]
+    add("gdn_chunk(prepare+scan)", lambda i: ops.chunk_gated_delta_rule(
+        *gin[i % NS], initial_state=states[i % NS], use_qk_l2norm_in_kernel=True, final_state_out=states[i % NS]),
+        24, "other", 0, "hbm", 24672.0 * T + sbytes)
+    add("gdn_chunk_fp8(prepare+scan)", lambda i: ops.chunk_gated_delta_rule(
+        *gin[i % NS], initial_state=states[i % NS], use_qk_l2norm_in_kernel=True, final_state_out=states[i % NS],
+        mma_dtype="fp8_e4m3"), 24, "other", 0, "hbm", 24672.0 * T + sbytes)
+    del gin
+    # the step's GDN layers run the chunk kernel WITH its front end (3 convs + SiLU + gate math inside the kernels): the
+    # projection is read once (16,416 B/token incl. the a / b gate inputs) and q / k / v / g / beta never reach HBM;
+    # algorithmic bytes per token: 16,416 (projection slice) + 8,192 (o) = 24,608 B + the state
     Dq, Dk, Dv = H * K, H * K, H * V
     cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
     ld = cols[4] + H
-    proj = rn(B, T, ld)
+    projs = [rn(B, T, ld) for _ in range(NS)]
     cw = [rn(D_, 1, 4) for D_ in (Dq, Dk, Dv)]
-    cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    css = [[rn(B, D_, 4) for D_ in (Dq, Dk, Dv)] for _ in range(NS)]
     A32, dt32 = torch.randn(H, device=device, generator=g_), torch.randn(H, device=device, generator=g_)
-    # the step's GDN layers run the chunk kernel WITH its front end (3 convs + SiLU + gate math inside the pre-pass): the
-    # projection is read once (16,416 B/token incl. the a / b gate inputs) and q / k / v / g / beta never reach HBM;
-    # algorithmic bytes per token: 16,416 (projection slice) + 8,192 (o) = 24,608 B + the state
-    add("gdn_chunk_fused(convs+gates+prepare+scan)", lambda: ops.gdn_chunk_fused(
-        proj, cols, cw, cs, cs, A32, dt32, H, K, V, initial_state=state, final_state_out=state), 20, 27, "hbm",
-        24608.0 * T + sbytes)
-    add("gdn_prologue(3 convs + gates)", lambda: ops.gdn_prologue(proj, cols, cw, cs, cs, A32, dt32, H, Dq, Dk, Dv),
-        50, 0, "hbm", 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2))
-    xo, wn = rn(B, T, H, V), rn(V)
-    add("rmsnorm_swish_gate", lambda: ops.rmsnorm_swish_gate_strided(xo, proj[..., Dq + Dk + Dv:], ld, wn, 1e-5),
-        50, 27, "hbm", 3.0 * T * H * V * 2)
-    xh, rh, wh = rn(B, T, 2048), rn(B, T, 2048), rn(2048)
-    add("add_rmsnorm(decoder layer)", lambda: ops.add_rmsnorm(xh, rh, wh, 1e-6), 50, 72, "hbm", 4.0 * T * 2048 * 2)
-    # decode-shape kernels (per decode token, not per prefill step)
+    add("gdn_chunk_fused(convs+gates+prepare+scan)", lambda i: ops.gdn_chunk_fused(
+        projs[i % NS], cols, cw, css[i % NS], css[i % NS], A32, dt32, H, K, V, initial_state=states[i % NS],
+        final_state_out=states[i % NS]), 24, "prefill", 27, "hbm", 24608.0 * T + sbytes)
+    add("gdn_prologue(3 convs + gates)", lambda i: ops.gdn_prologue(projs[i % NS], cols, cw, css[i % NS], css[i % NS], A32, dt32,
+                                                                    H, Dq, Dk, Dv),
+        48, "other", 0, "hbm", 2.0 * T * 8192 * 2 + T * H * (2 * 2 + 4 + 2))
+    xos, wn = [rn(B, T, H, V) for _ in range(NS)], rn(V)
+    add("rmsnorm_swish_gate", lambda i: ops.rmsnorm_swish_gate_strided(xos[i % NS], projs[i % NS][..., Dq + Dk + Dv:], ld, wn, 1e-5),
+        48, "prefill", 27, "hbm", 3.0 * T * H * V * 2)
+    # SWA layer of the step, called the way cache.attend calls it (cache.py: StaticSlidingWindowLayerPrealloc.attend): q / k /
+    # v are strided views of the fused qkv projection, M-RoPE fused (rope=), ring append in the combine launch (append=True):
+    # rope pre-pass + attention + combine are all inside.  T queries over a full ring (W-1 cached keys) + T new keys;
+    # 8192*min(p+1,W) FLOP/token/layer
+    NSW = 4
+    rings = [(rn(B, Hkv, C, d), rn(B, Hkv, C, d)) for _ in range(NSW)]
+    pos_dev = torch.full((1,), 10 * window, dtype=torch.int64, device=device)
+    nq, nkv = Hq * d, Hkv * d
+
+    def qkv_views(Tn, Bn=B):
+        qkv = rn(Bn, Tn, nq + 2 * nkv)
+        return (qkv[..., :nq].unflatten(-1, (Hq, d)), qkv[..., nq:nq + nkv].unflatten(-1, (Hkv, d)),
+                qkv[..., nq + nkv:].unflatten(-1, (Hkv, d)))
+    qkvs = [qkv_views(T) for _ in range(NSW)]
+    pid = torch.arange(10 * window, 10 * window + T, device=device)[None, None, :].expand(3, B, T).contiguous()
+    inv_freq = 1.0 / (1e6 ** (torch.arange(0, d, 2, device=device, dtype=torch.float32) / d))
+    cos, sin = ops.rope_tables(pid, inv_freq, 1.0)
+    rope = (cos, sin, (16, 24, 24))
+    add("swa_prefill(rope pre-pass + attention + combine with append)", lambda i: ops.swa_forward(
+        *qkvs[i % NSW], window=window, scaling=d ** -0.5, k_cache=rings[i % NSW][0], v_cache=rings[i % NSW][1],
+        pos_dev=pos_dev, rope=rope, append=True), 24, "prefill", 9, "mfma", 4.0 * Hq * d * window * T)
+    add("swa_attention_only(rotated inputs, no append)", lambda i: ops.swa_forward(
+        *qkvs[i % NSW], window=window, scaling=d ** -0.5, k_cache=rings[i % NSW][0], v_cache=rings[i % NSW][1],
+        pos_dev=pos_dev), 24, "other", 0, "mfma", 4.0 * Hq * d * window * T)
+    add("swa_cache_append(stand-alone launch; the step appends in the combine launch)", lambda i: ops.swa_cache_append(
+        qkvs[i % NSW][1], qkvs[i % NSW][2], rings[i % NSW][0], rings[i % NSW][1], pos_dev=pos_dev), 48, "other", 0, "hbm",
+        4.0 * T * Hkv * d * 2)
+    add("rope_tables", lambda i: ops.rope_tables(pid, inv_freq, 1.0), 48, "prefill", 1, "hbm", 3.0 * T * (8 + 2 * 2 * d))
+    add("counter_add", lambda i: ops.counter_add(pos_dev, 0), 48, "prefill", 1, "hbm", 16.0)
+    # decoder-layer glue: residual add + RMSNorm (2 per layer + the final norm), SwiGLU gate
+    xhs, rhs, wh = [rn(B, T, 2048) for _ in range(NS)], [rn(B, T, 2048) for _ in range(NS)], rn(2048)
+    add("add_rmsnorm(decoder layer)", lambda i: ops.add_rmsnorm(xhs[i % NS], rhs[i % NS], wh, 1e-6), 48, "prefill", 73, "hbm",
+        4.0 * T * 2048 * 2)
+    I_ = 11008
+    gus = [rn(B, T, 2 * I_) for _ in range(NS)]
+    add("silu_mul(SwiGLU gate)", lambda i: ops.silu_mul(gus[i % NS]), 48, "prefill", 36, "hbm", 3.0 * T * I_ * 2)
+    del gus, xhs, rhs, xos
+    # decode-shape kernels (per decode token)
     q1, k1, v1, g1, b1 = gdn_inputs(1)
-    add("gdn_recurrent(decode)", lambda: ops.fused_recurrent_gated_delta_rule(
-        q1, k1, v1, g1, b1, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        100, 27, "hbm", 24672.0 + sbytes)
+    add("gdn_recurrent(decode)", lambda i: ops.fused_recurrent_gated_delta_rule(
+        q1, k1, v1, g1, b1, initial_state=states[i % NS], use_qk_l2norm_in_kernel=True, final_state_out=states[i % NS]),
+        96, "other", 0, "hbm", 24672.0 + sbytes)
     proj1 = rn(B, 1, ld)
     cols6 = (cols[0], cols[1], cols[2], Dq + Dk + Dv, cols[3], cols[4])
-    add("gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)", lambda: ops.gdn_decode_step(
-        proj1, cols6, cw, cs, A32, dt32, wn, 1e-5, state, H, K, V, K ** -0.5), 100, 0, "hbm",
+    add("gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)", lambda i: ops.gdn_decode_step(
+        proj1, cols6, cw, css[i % NS], A32, dt32, wn, 1e-5, states[i % NS], H, K, V, K ** -0.5), 96, "decode", 27, "hbm",
         2.0 * ld + sbytes + 2.0 * H * V)
-    qd, kd1, vd1 = rn(B, 1, Hq, d), rn(B, 1, Hkv, d), rn(B, 1, Hkv, d)
-    add("swa_decode", lambda: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=kc, v_cache=vc,
-                                              pos_dev=pos_dev), 100, 9, "hbm", 1024.0 * window)
+    qd, kd1, vd1 = qkv_views(1)
+    add("swa_decode", lambda i: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=rings[i % NSW][0],
+                                                v_cache=rings[i % NSW][1], pos_dev=pos_dev, append=True), 96, "decode", 9, "hbm",
+        1024.0 * window)
+    x1, r1 = rn(B, 1, 2048), rn(B, 1, 2048)
+    add("add_rmsnorm(decode token)", lambda i: ops.add_rmsnorm(x1, r1, wh, 1e-6), 96, "decode", 73, "hbm", 4.0 * 2048 * 2)
     # decode-step projections (M = 1 weight streams; outside SURVEY.md section 8's rows, listed for the decode leg)
     for nm, N_, K_, per in (("gdn in-proj", 12320, 2048, 27), ("mlp gate|up", 22016, 2048, 36),
                             ("mlp down", 2048, 11008, 36), ("gdn o_proj", 2048, 4096, 27), ("lm_head", 151936, 2048, 1)):
         w_, x_ = rn(N_, K_), rn(1, 1, K_)
-        add(f"decode linear {nm} [{N_}x{K_}]", lambda w_=w_, x_=x_: ops.linear(x_, w_), 50, 0, "hbm",
+        add(f"decode linear {nm} [{N_}x{K_}]", lambda i, w_=w_, x_=x_: ops.linear(x_, w_), 48, "decode", per, "hbm",
             2.0 * N_ * K_ + 2.0 * (N_ + K_))
-        res_key = f"decode linear {nm} [{N_}x{K_}]"
-        if res_key in res:
-            res[res_key]["launches_per_decode_token"] = per
         del w_, x_
-    # batched streams (8 sequences per GPU in one call): the same kernels with 8x the work per launch -- shows that
-    # the low fractions at B=1 come from the size of a 256-token step, not from the kernels
+    del projs, css
+    # batched streams (8 sequences per GPU in one call): the same kernels with 8x the work per launch
     Bb = 8
-    qb, kb_, vb_ = rn(Bb, T, H, K), rn(Bb, T, H, K), rn(Bb, T, H, V)
-    betab = torch.rand(Bb, T, H, device=device, generator=g_).to(torch.bfloat16)
-    gb_ = torch.nn.functional.logsigmoid(torch.randn(Bb, T, H, device=device, generator=g_))
+    ginb = gdn_inputs(T, Bb)
     stateb = torch.randn(Bb, H, K, V, device=device, generator=g_).to(torch.bfloat16)
-    add("gdn_chunk@B=8", lambda: ops.chunk_gated_delta_rule(
-        qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb),
-        10, 0, "hbm", Bb * (24672.0 * T + sbytes))
-    add("gdn_chunk_fp8@B=8", lambda: ops.chunk_gated_delta_rule(
-        qb, kb_, vb_, gb_, betab, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb,
-        mma_dtype="fp8_e4m3"), 10, 0, "hbm", Bb * (24672.0 * T + sbytes))
-    kcb, vcb = rn(Bb, Hkv, C, d), rn(Bb, Hkv, C, d)
-    qsb, knb, vnb = rn(Bb, T, Hq, d), rn(Bb, T, Hkv, d), rn(Bb, T, Hkv, d)
-    add("swa_prefill@B=8", lambda: ops.swa_forward(qsb, knb, vnb, window=window, scaling=d ** -0.5, k_cache=kcb,
-                                                   v_cache=vcb, pos_dev=pos_dev), 10, 0, "mfma",
-        Bb * 4.0 * Hq * d * window * T)
-    del qb, kb_, vb_, kcb, vcb, qsb, knb, vnb
-    # throughput-regime shapes (one-shot 4096-token prefill, BASELINE.json configs[1]); not part of the step
+    add("gdn_chunk@B=8", lambda i: ops.chunk_gated_delta_rule(
+        *ginb, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb),
+        10, "other", 0, "hbm", Bb * (24672.0 * T + sbytes))
+    add("gdn_chunk_fp8@B=8", lambda i: ops.chunk_gated_delta_rule(
+        *ginb, initial_state=stateb, use_qk_l2norm_in_kernel=True, final_state_out=stateb,
+        mma_dtype="fp8_e4m3"), 10, "other", 0, "hbm", Bb * (24672.0 * T + sbytes))
+    projb = rn(Bb, T, ld)
+    csb = [rn(Bb, D_, 4) for D_ in (Dq, Dk, Dv)]
+    add("gdn_chunk_fused@B=8", lambda i: ops.gdn_chunk_fused(projb, cols, cw, csb, csb, A32, dt32, H, K, V, initial_state=stateb,
+                                                             final_state_out=stateb), 10, "other", 0, "hbm",
+        Bb * (24608.0 * T + sbytes))
+    ringb = (rn(Bb, Hkv, C, d), rn(Bb, Hkv, C, d))
+    qkvb = qkv_views(T, Bb)
+    pidb = pid.expand(3, Bb, T).contiguous()
+    cosb, sinb = ops.rope_tables(pidb, inv_freq, 1.0)
+    add("swa_prefill@B=8", lambda i: ops.swa_forward(*qkvb, window=window, scaling=d ** -0.5, k_cache=ringb[0], v_cache=ringb[1],
+                                                     pos_dev=pos_dev, rope=(cosb, sinb, (16, 24, 24)), append=True),
+        10, "other", 0, "mfma", Bb * 4.0 * Hq * d * window * T)
+    del ginb, projb, csb, ringb, qkvb
+    # throughput-regime shapes: 4096-token calls (BASELINE.json configs[1]: fresh cache, causal; configs[3]: bulk prefill over
+    # a FULL ring at >= 128K context, the cfg3_512k_prefill leg); not part of the step
     TL = 4096
-    qL, kL, vL, gL, bL = gdn_inputs(TL)
-    add("gdn_chunk@T=4096", lambda: ops.chunk_gated_delta_rule(
-        qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
-        5, 0, "hbm", 24672.0 * TL + sbytes)
-    add("gdn_chunk_fp8@T=4096", lambda: ops.chunk_gated_delta_rule(
-        qL, kL, vL, gL, bL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
-        5, 0, "hbm", 24672.0 * TL + sbytes)
-    qsL, knL, vnL = rn(B, TL, Hq, d), rn(B, TL, Hkv, d), rn(B, TL, Hkv, d)
-    add("swa_prefill@T=4096(causal)", lambda: ops.swa_forward(qsL, knL, vnL, window=8192, scaling=d ** -0.5),
-        5, 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
+    ginL = gdn_inputs(TL)
+    add("gdn_chunk@T=4096", lambda i: ops.chunk_gated_delta_rule(
+        *ginL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state),
+        5, "other", 0, "hbm", 24672.0 * TL + sbytes)
+    add("gdn_chunk_fp8@T=4096", lambda i: ops.chunk_gated_delta_rule(
+        *ginL, initial_state=state, use_qk_l2norm_in_kernel=True, final_state_out=state, mma_dtype="fp8_e4m3"),
+        5, "other", 0, "hbm", 24672.0 * TL + sbytes)
+    projL = rn(B, TL, ld)
+    csL = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    add("gdn_chunk_fused@T=4096", lambda i: ops.gdn_chunk_fused(projL, cols, cw, csL, csL, A32, dt32, H, K, V, initial_state=state,
+                                                                final_state_out=state), 5, "other", 0, "hbm",
+        24608.0 * TL + sbytes)
+    qkvL = qkv_views(TL)
+    add("swa_prefill@T=4096(causal)", lambda i: ops.swa_forward(*qkvL, window=8192, scaling=d ** -0.5),
+        5, "other", 0, "mfma", 4.0 * Hq * d * (TL * (TL + 1) / 2))
+    pidL = torch.arange(40 * window, 40 * window + TL, device=device)[None, None, :].expand(3, B, TL).contiguous()
+    cosL, sinL = ops.rope_tables(pidL, inv_freq, 1.0)
+    add("swa_prefill@T=4096(full ring, rope + append)", lambda i: ops.swa_forward(
+        *qkvL, window=window, scaling=d ** -0.5, k_cache=rings[0][0], v_cache=rings[0][1], pos_dev=pos_dev,
+        rope=(cosL, sinL, (16, 24, 24)), append=True), 5, "other", 0, "mfma", 4.0 * Hq * d * window * TL)
+    del ginL, projL, qkvL
     # vision tower (not part of the text-stack step): 8 frames of 32 x 32 patches, 16 heads x 80,
     # rotary embedding folded in; a window layer (64-patch segments) and a full-attention layer (one segment per frame).
     # flops = 4 * d * H * sum(len^2) (non-causal)
@@ -233,43 +379,31 @@ def kernel_timings(device, chunk, window, only=None):
     vcos, vsin = (torch.randn(frames * per, dv, device=device, generator=g_) for _ in range(2))
     for tag, seg in (("window layer, 64-patch segments", 64), ("full layer, 1024-patch segments", 1024)):
         cu = torch.arange(0, frames * per + 1, seg, dtype=torch.int32, device=device)
-        add(f"vision_attn({tag})@8 frames", lambda cu=cu, seg=seg: ops.vision_window_attention(
-            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg, rope=(vcos, vsin)), 20, 0, "mfma",
+        add(f"vision_attn({tag})@8 frames", lambda i, cu=cu, seg=seg: ops.vision_window_attention(
+            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg, rope=(vcos, vsin)), 20, "other", 0, "mfma",
             4.0 * dv * Hv * (frames * per // seg) * seg * seg)
     return res
 
 
 def pmc_traffic(kernel_name, chunk, window):
-    """HBM-side bytes per launch of a hot-path kernel from the committed rocprofv3 --pmc passes
+    """HBM-side bytes per call of a hot-path kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, produced by tools/collect_profiles.sh on this same command's kernels at the
     default bench shapes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot
     run the PMC passes itself, so the newest committed measurement is attached; null when the shapes differ."""
-    import glob
     if chunk != 256 or window != 4096:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
+    path = _newest_profile("r*_pmc_traffic.json")
+    want = PROFILE_ROWS.get(kernel_name)
+    if path is None or not want:
         return None
-    k = json.load(open(files[-1]))["kernels"]
-    want = {
-        "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
-        "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, true>", 32768),
-                                                      ("ivl::gdn_chunk_scan_kernel<2, false>", 65536)],
-        "swa_prefill": [("ivl::swa_prefill_kernel", 196608), ("ivl::swa_combine_kernel<8, true>", 270336)],
-        "gdn_prologue(3 convs + gates)": [("ivl::gdn_prologue_kernel", 69632)],
-        "add_rmsnorm(decoder layer)": [("ivl::add_rmsnorm_kernel", 65536)],
-        "rmsnorm_swish_gate": [("ivl::rmsnorm_gate_strided_kernel", 131072)],
-        "gdn_recurrent(decode)": [("ivl::gdn_recurrent_kernel", 32768)],
-    }.get(kernel_name)
-    if not want:
-        return None
+    k = json.load(open(path))["kernels"]
     parts = []
     for base, grid in want:          # kernel names carry template arguments: match on the prefix and the grid size
         hit = [n for n in k if n.startswith(base) and n.endswith(f"@grid{grid}")]
         if len(hit) != 1:
             return None
         parts.append(hit[0])
-    return {"hbm_bytes": sum(k[p_]["hbm_bytes"] for p_ in parts), "source": os.path.basename(files[-1]),
+    return {"hbm_bytes": sum(k[p_]["hbm_bytes"] for p_ in parts), "source": os.path.basename(path),
             "launches": parts}
 
 
@@ -387,8 +521,32 @@ def main():
 
     # the path's only collective: gather the last-position logits of every sequence
     _, logits = step.hidden, step.logits
-    all_logits = ivd.gather_last_logits(logits[:, -1].float().contiguous(), [B_local] * world)
+    last = logits[:, -1].float().contiguous()
+    all_logits = ivd.gather_last_logits(last, [B_local] * world)              # first call: communicator set-up included
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    all_logits = ivd.gather_last_logits(last, [B_local] * world)
+    torch.cuda.synchronize()
+    allgather_ms = ivd.max_over_ranks((time.perf_counter() - tg) * 1e3, device)
     finite = bool(torch.isfinite(all_logits).all())
+    # what the collective actually ran on (N > 1): backend, one record per rank, the gathered shape.  Ranks must sit on
+    # distinct GPUs under RCCL (the gloo debug mode IVL_DIST_BACKEND=gloo may stack ranks on one device).
+    dist_info = None
+    if world > 1:
+        dist_info = ivd.describe_ranks(device)
+        dist_info.update(gathered_logits_shape=list(all_logits.shape), allgather_ms=allgather_ms,
+                         logits_rows_differ_across_ranks=bool(world < 2 or not torch.equal(all_logits[0], all_logits[1])))
+        if dist_info["backend"] == "nccl":
+            assert dist_info["distinct_devices"] == world, dist_info
+        assert tuple(all_logits.shape) == (B_local * world, cfg.vocab_size), all_logits.shape
+
+    # per-kernel durations inside the real step, live (rank 0; outside the timed region; the cache advances like in a step)
+    live_prefill = live_decode = None
+    if rank == 0 and not args.no_kernel_timing:
+        try:
+            live_prefill = profile_replays(lambda: step.step(frames[0]))
+        except Exception as e:                       # profiler unavailable: the committed rocprofv3 trace is used instead
+            print(f"[bench] torch.profiler unavailable ({type(e).__name__}: {e})", file=sys.stderr)
 
     # ---- decode leg (separately timed) ------------------------------------------------------------
     dec = GraphedDecode(model, cache, B_local)
@@ -404,6 +562,11 @@ def main():
     torch.cuda.synchronize()
     ivd.barrier()
     dec_elapsed = ivd.max_over_ranks(time.perf_counter() - t1, device)
+    if rank == 0 and live_prefill is not None:
+        try:
+            live_decode = profile_replays(dec.step, n=8)
+        except Exception as e:
+            print(f"[bench] torch.profiler unavailable for the decode graph ({type(e).__name__}: {e})", file=sys.stderr)
     mem_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
     # ---- fp8 leg (rank 0, reported beside the headline, never mixed into `value`): BASELINE.json configs[4] -- the same
@@ -441,6 +604,34 @@ def main():
                "frames_per_s_at_256_tokens": 1.0 / t8, "frame_budget_ms_24fps": 1000.0 / 24, "logits_finite": fin8}
         model.set_mma_dtype(None)
         del step8, dec8, cache8
+
+    # ---- configs[3] leg, single-GPU half (rank 0, N=1; reported beside the headline): bulk prefill of ONE long sequence in
+    #      4096-token calls over a FULL 4096-key ring, continuing from the >= 128K-token context the legs above left in `cache`
+    #      (SURVEY.md 8d cfg4 "128 calls of T=4096, state carried"; reference claim README.md:51).  Eager launches.
+    cfg3 = None
+    if rank == 0 and world == 1 and not args.no_cfg3:
+        Tb, n_warm, n_timed = 4096, 2, 8
+        ctx0 = cache.get_seq_length()
+        xb = (torch.randn(1, Tb, cfg.hidden_size, device=device, generator=gen) * 0.02).to(torch.bfloat16)
+        times3 = []
+        with torch.no_grad():
+            for r in range(n_warm + n_timed):
+                start3 = cache.get_seq_length()
+                pid3 = torch.arange(start3, start3 + Tb, device=device)[None, None, :].expand(3, 1, Tb).contiguous()
+                torch.cuda.synchronize()
+                tA = time.perf_counter()
+                _, lg3 = model(inputs_embeds=xb, position_ids=pid3, past_key_values=cache, logits_to_keep=1)
+                torch.cuda.synchronize()
+                if r >= n_warm:
+                    times3.append(time.perf_counter() - tA)
+        mean3 = sum(times3) / len(times3)
+        cfg3 = {"workload": "configs[3], one GPU's share: bulk prefill of one long sequence in 4096-token calls (eager launches) over a "
+                            "full 4096-key ring with carried GDN state, starting at the context the streaming + decode legs reached",
+                "context_start": ctx0 + n_warm * Tb, "context_end": cache.get_seq_length(), "calls_timed": n_timed,
+                "tokens_per_call": Tb, "ms_per_call": mean3 * 1e3, "ms_per_call_min": min(times3) * 1e3,
+                "prefill_tok_s": Tb / mean3, "logits_finite": bool(torch.isfinite(lg3.float()).all()),
+                "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
+        del xb
 
     # ---- configs[1] leg (rank 0, N=1; reported beside the headline, never mixed into `value`): one 4096-token
     #      prefill call on a fresh cache (chunk path over 64 chunks; SWA purely causal) + 128 graphed decode steps
@@ -481,7 +672,7 @@ def main():
 
     kernels, cpu = None, None
     if rank == 0 and not args.no_kernel_timing:
-        kernels = kernel_timings(device, T, args.window)
+        kernels = kernel_timings(device, T, args.window, live_prefill=live_prefill, live_decode=live_decode)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, args.window)
     ivd.barrier()
@@ -505,24 +696,47 @@ def main():
             "logits_finite": finite, "peak_mem_gib": round(mem_gb, 2),
         }
         if kernels is not None:
-            def step_ms(r):
-                return r["ms"] * r["launches_per_step"]
-            prefill_kernels = {k: v for k, v in kernels.items() if v["launches_per_step"] > 0 and "decode" not in k}
-            dom = max(prefill_kernels, key=lambda k: step_ms(prefill_kernels[k]))
+            # a kernel's cost inside the step = calls per step x its duration INSIDE the real step where the committed
+            # rocprofv3 trace has it (in_step_us), else the live HIP-event time over rotating inputs
+            def call_ms(r):
+                return r["in_step_us"] * 1e-3 if "in_step_us" in r else r["ms"]
+            prefill_kernels = {k: v for k, v in kernels.items() if v["phase"] == "prefill"}
+            decode_kernels = {k: v for k, v in kernels.items() if v["phase"] == "decode"}
+            dom = max(prefill_kernels, key=lambda k: call_ms(prefill_kernels[k]) * prefill_kernels[k]["launches_per_step"])
             r = kernels[dom]
             tr = pmc_traffic(dom, T, args.window)
-            out["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
-                               "unit": r["unit"], "frac": r["frac"], "traffic": tr["hbm_bytes"] if tr else None,
+            work = r.get("alg_bytes", r.get("alg_flops"))
+            # `achieved` / `frac` come from the kernel's duration INSIDE the timed workload's step (live torch.profiler
+            # records of the replayed graph; falls back to the HIP-event micro-benchmark over rotating inputs).  The
+            # micro-benchmark figure and the committed rocprofv3 trace are reported beside it; all three must agree.
+            in_us = r.get("in_step_us")
+            dur_ms = in_us * 1e-3 if in_us is not None else r["ms"]
+            ach = work / (dur_ms * 1e-3) / (1e9 if r["bound"] == "hbm" else 1e12)
+            out["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": ach, "peak": r["peak"],
+                               "unit": r["unit"], "frac": ach / r["peak"], "traffic": tr["hbm_bytes"] if tr else None,
                                "traffic_source": tr["source"] if tr else None,
-                               "algorithmic_per_launch": r.get("alg_bytes", r.get("alg_flops")),
-                               "avg_launch_ms": r["ms"], "launches_per_step": r["launches_per_step"]}
+                               "algorithmic_per_launch": work, "avg_launch_ms": dur_ms,
+                               "duration_source": r.get("in_step_source", "HIP events, graph of launches over rotating inputs"),
+                               "launches_per_step": r["launches_per_step"],
+                               "microbench_launch_ms": r["ms"], "microbench_frac": r["frac"],
+                               "rocprofv3_in_step_us": r.get("in_step_us_rocprofv3"),
+                               "rocprofv3_source": r.get("in_step_rocprofv3_source")}
             out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                               for k, v in kernels.items()}
-            out["hot_path_ms_per_step"] = sum(step_ms(v) for v in prefill_kernels.values())
+            out["hot_path_ms_per_step"] = sum(call_ms(v) * v["launches_per_step"] for v in prefill_kernels.values())
+            out["hot_path_ms_per_step_live"] = sum(v["ms"] * v["launches_per_step"] for v in prefill_kernels.values())
+            out["hot_path_ms_per_decode_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
+                                                      for k, v in decode_kernels.items() if not k.startswith("decode linear"))
+            out["decode_linear_ms_per_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
+                                                    for k, v in decode_kernels.items() if k.startswith("decode linear"))
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if fp8 is not None:
             out["fp8_e4m3"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in fp8.items()}
+        if cfg3 is not None:
+            out["cfg3_512k_prefill"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg3.items()}
+        if dist_info is not None:
+            out["dist"] = dist_info
         if cfg1 is not None:
             out["cfg1_4k_prefill_decode"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg1.items()}
         print(json.dumps(out))

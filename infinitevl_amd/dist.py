@@ -68,6 +68,22 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def describe_ranks(device: torch.device) -> dict:
+    """What the process group actually runs on: backend, world size and one record per rank (rank, local device index, PCI
+    bus id, device name) collected with all_gather_object -- so that a multi-GPU bench line proves where its ranks sat."""
+    rec = {"rank": dist.get_rank(), "device_index": device.index, "pci_bus_id": None, "name": None}
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        rec["name"] = pr.name
+        ids = [getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        rec["pci_bus_id"] = (":".join(f"{int(x):02x}" for x in ids) if all(x is not None for x in ids)
+                             else str(getattr(pr, "uuid", device.index)))
+    recs = [None] * dist.get_world_size()
+    dist.all_gather_object(recs, rec)
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": recs,
+            "distinct_devices": len({r["pci_bus_id"] for r in recs})}
+
+
 def gather_last_logits(logits_local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     """All-gather last-position logits [B_local, V] from every rank into [sum(counts), V] (rank order
     = batch order of shard_batch).  Ragged shards are padded to max(counts) for the collective."""

@@ -388,6 +388,8 @@ def _gloo_worker(rank, world, port, q):
     full = ivd.gather_last_logits(local, counts)
     ivd.barrier()
     mx = ivd.max_over_ranks(1.0 + r, torch.device("cpu"))
+    info = ivd.describe_ranks(torch.device("cpu"))
+    assert info["backend"] == "gloo" and info["world"] == w and [d["rank"] for d in info["devices"]] == list(range(w))
     q.put((r, full[:, 0].tolist(), mx))
     torch.distributed.destroy_process_group()
 

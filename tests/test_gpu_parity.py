@@ -1463,6 +1463,33 @@ def test_sequence_parallel_prefill_two_ranks_bit_exact():
     assert r.returncode == 0 and "SP_CHECK PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_bench_two_ranks_reports_what_the_collective_ran_on():
+    """bench.py --gpus 2 (self-spawned under torch.distributed.run) with the gloo debug backend, both ranks on this GPU: the
+    JSON line carries a `dist` object (backend, world, one record per rank with device index and PCI bus id, the gathered
+    logits' shape, the all-gather time) - the fields that make a driver-run multi-GPU line checkable from its output.  Under
+    RCCL the same code asserts that the ranks sit on distinct devices."""
+    import json as _json
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IVL_DIST_BACKEND="gloo", IVL_NO_TUNABLEOP="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--layers", "4", "--context", "8192", "--decode-steps", "2", "--no-cpu-baseline", "--no-cfg1", "--no-cfg3",
+                        "--no-fp8", "--no-kernel-timing"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = _json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 and out["scaling"] == "weak"
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world"] == 2 and len(d["devices"]) == 2
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and all(x["pci_bus_id"] for x in d["devices"])
+    assert d["gathered_logits_shape"] == [2, 151936] and d["allgather_ms"] > 0 and d["logits_rows_differ_across_ranks"]
+    assert d["distinct_devices"] == 1          # two gloo ranks stacked on one GPU; RCCL runs assert == world
+    assert out["logits_finite"] and out["value"] > 0
+
+
 def test_full_attention_layer_with_dynamic_cache_equals_one_causal_call():
     """A "full_attention" layer type (strm:548-550 fallback): the module goes through the growing DynamicLayer cache
     and plain causal attention; two chunks fed through the cache == one call over the whole sequence."""
