@@ -49,20 +49,27 @@ constexpr int GV = 256;       // value head dim
 constexpr int G_SEG_CHUNKS = 64;   // chunks per workspace segment (4096 tokens)
 
 // ---- workspace record per (batch*head, chunk) ------------------------------------------------------------------
-// 56 fragment blocks (1 KB each in bf16, 512 B in fp8 e4m3), then e^gamma, then u (always bf16: it is an accumulator input)
+// 54 fragment blocks (1 KB each in bf16, 512 B in fp8 e4m3), then e^gamma / beta, then 6 bf16 blocks of Tu
 //   WN  : -(bf16(w) e^gamma)            blocks (m, s)  = 4 m + s    rows: time   contraction: k
 //   QH  : q_hat                         blocks (m, s)  = 4 m + s    rows: time   contraction: k
 //   KDT : (k_hat e^{gl-gamma})^T        blocks (t, s2) = 2 t + s2   rows: k      contraction: time
-//   AQK : tril((q k^T) Gamma)           blocks (m, s2) = 2 m + s2   rows: time   contraction: time
-//   EG  : f32 e^gamma[64]; EGL: f32 e^gamma_last
-//   U   : bf16 u in the scan's accumulator layout: 8-byte piece ((slab, m, g), j) at ((16 slab + 4 m + g) * 16 + j) * 8
-//         = u[16m + 4g + 0..3][16 slab + j]   (32 KB)
+//   AQK : tril((q k^T) Gamma)           blocks tri_blk(m, s2)       rows: time   contraction: time
+//   EG  : f32 e^gamma[64]; EGL: f32 e^gamma_last; BETA: bf16 beta[64] (0 for the padded rows of a ragged last chunk)
+//   TU  : bf16((I + L Gamma)^-1)        blocks tri_blk(m, s2)       rows: time   contraction: time   (always bf16: u = Tu (beta v)
+//         is rounded to bf16 like the reference's, whatever the operand format of the scan's products)
+// A lower-triangular 64 x 64 matrix has six non-zero 16 x 32 blocks: (m, s2) = (0,0) (1,0) (2,0) (2,1) (3,0) (3,1); the two
+// blocks strictly above the diagonal are neither stored nor multiplied.
+// Round 3: u itself is no longer part of the record.  The value side (v -> [conv + SiLU] -> beta v -> u = Tu (beta v)) runs in
+// the scan's V waves, one chunk ahead of the state waves (u does not depend on the state): the pre-pass neither loads v nor
+// writes the 32 KB of u per chunk, and the scan reads v where it read u.
 template <bool F8>
 struct Rec {
   static constexpr int BLK = F8 ? 512 : 1024;       // bytes per fragment block; a piece = BLK / 64 bytes per lane
-  static constexpr int WN = 0, QH = 16 * BLK, KDT = 32 * BLK, AQK = 48 * BLK, EG = 56 * BLK, EGL = EG + 256, U = EG + 1024;
-  static constexpr size_t STRIDE = U + 32768;       // bf16: 91,136   fp8: 62,464
+  static constexpr int WN = 0, QH = 16 * BLK, KDT = 32 * BLK, AQK = 48 * BLK, EG = 54 * BLK, EGL = EG + 256, BETA = EG + 512;
+  static constexpr int TU = EG + 1024;
+  static constexpr size_t STRIDE = TU + 6 * 1024;   // bf16: 62,464   fp8: 34,816
 };
+__host__ __device__ constexpr int tri_blk(int m, int s2) { return m < 2 ? m : 2 + 2 * (m - 2) + s2; }
 
 __device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) {
   mfma_bf16x8 r;
@@ -97,18 +104,12 @@ __device__ __forceinline__ void put_piece(unsigned char* base, int idx, float a0
 // ==================================================================================================
 constexpr int P_LDK = 136;                         // bf16 elements per row of k_hat / q_hat / beta k_hat (272 B)
 constexpr int P_LDF = 68;                          // f32 elements per row of L / T
-constexpr int P_LDV = 264;                         // bf16 elements per row of beta v (528 B)
-constexpr int P_LDT = 72;                          // bf16 elements per row of Tu (144 B)
 constexpr int P_KH = 0;                            // k_hat            [64][136] bf16
 constexpr int P_QH = P_KH + GC * P_LDK * 2;        // q_hat            [64][136]
-constexpr int P_VB = 0;                            // bf16(beta v)     [64][264] row-major, written over k_hat / q_hat once
-                                                   //   they are dead (B operands via the LDS transpose read)
 constexpr int P_KB = P_QH + GC * P_LDK * 2;        // bf16(beta k_hat) [64][136]
 constexpr int P_L = P_KB + GC * P_LDK * 2;         // L, inverted IN PLACE to T = (I+L)^-1   [64][68] f32
-constexpr int P_TU = P_L + GC * P_LDF * 4;         // bf16(Tu)         [64][72]
-constexpr int P_SM = P_TU + GC * P_LDT * 2;        // gam[64], eg[64], dec[64], beta[64]
-constexpr int P_BYTES = P_SM + 4 * GC * 4;         // 79,872: two workgroups per CU
-static_assert(GC * P_LDV * 2 <= 2 * GC * P_LDK * 2, "beta v must fit in the k_hat / q_hat region");
+constexpr int P_SM = P_L + GC * P_LDF * 4;         // gam[64], eg[64], dec[64], beta[64]
+constexpr int P_BYTES = P_SM + 4 * GC * 4;         // 70,656: two workgroups per CU
 static_assert(2 * P_BYTES <= 160 * 1024, "pre-pass LDS budget (2 workgroups per CU)");
 
 // sum over the 16 lanes of a DPP row (the 16 threads that share one q / k row), result in every lane
@@ -206,16 +207,14 @@ __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x
 
 template <bool F8, bool FUSED>
 __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ g,
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using R = Rec<F8>;
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
   bf16_t* s_kb = (bf16_t*)(smem + P_KB);
-  bf16_t* s_vb = (bf16_t*)(smem + P_VB);
   float* s_L = (float*)(smem + P_L);          // L, then T in place
-  bf16_t* s_tu = (bf16_t*)(smem + P_TU);
   float* s_gam = (float*)(smem + P_SM);
   float* s_eg = s_gam + GC;
   float* s_dec = s_eg + GC;
@@ -237,22 +236,22 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * R::STRIDE;
 
   // ---- P0: every global load of the chunk is issued up front (clamped rows, zeroed later) ------------------
-  // plain : thread -> rows r0, r0 + 32 of q and k, 16-byte column octet; waves 4-7 also rows vr + 8 i of v
-  // fused : waves 0-3 -> rows 4 r0 .. 4 r0 + 3 of q and k (r0 < 16), waves 4-7 -> rows 8 vr .. 8 vr + 7 of v: runs of
-  //         consecutive tokens, so that the three tokens in front of a run are loaded once
-  const int oct = tid & 15, r0 = FUSED ? (tid >> 4) & 15 : tid >> 4;
-  constexpr int NQK = FUSED ? 4 : 2;                 // q / k rows per thread
-  u32x4 kraw[NQK], qraw[NQK];
+  // plain : thread -> rows r0, r0 + 32 of q AND k (r0 = tid / 16), 16-byte column octet
+  // fused : waves 0-3 -> rows 4 r0 .. 4 r0 + 3 of q, waves 4-7 -> the same rows of k (r0 < 16): runs of consecutive tokens, so
+  //         that the three tokens in front of a run are loaded once; conv + SiLU of the run; the value side is not touched
+  //         here at all (round 3: it belongs to the scan's V waves)
+  const int oct = tid & 15;
+  const bool is_k = wave_u >= 4;                     // fused: the array this wave converts (wave-uniform)
+  // SIMD s hosts waves s and s + 4.  Three pieces of single-wave work sit in front of B1: the conv-state hand-over of q (the
+  // threads that hold rows 0-3: wave 0), of k (wave 6: the k runs are rotated by 8) and the gate / cumsum step P1a (wave 1):
+  // three different SIMDs.
+  const int r0 = FUSED ? (is_k ? ((tid >> 4) + 8) & 15 : (tid >> 4) & 15) : tid >> 4;
+  constexpr int NQK = FUSED ? 4 : 2;                 // rows per thread (fused: of ONE array)
+  u32x4 kraw[NQK], qraw[NQK];                        // fused: only the wave's own array is populated
   bf16_t braw[NQK];
-  u32x4 vraw[8];                                     // waves 4-7: the chunk's v tile, 8 x 16 bytes per thread
-  // SIMD s hosts waves s and s + 4.  Three pieces of single-wave work sit in front of B1: the conv-state hand-over of q / k
-  // (the threads that hold rows 0-3: wave 0), the hand-over of v (the threads with vr == 0) and the gate / cumsum step P1a.
-  // All three on SIMD 0 (waves 0 and 4) made that SIMD arrive at B1 5,500 cycles after the others; now P1a runs on wave 1
-  // and the v run that starts at row 0 belongs to wave 7.
-  const int t2v = tid - 256, voct = t2v & 31, vr = ((t2v >> 5) + 2) & 7;
   constexpr int P1A_WAVE = 1;
-  // wave 0 also fetches the chunk's gate inputs here (consumed in P1a, behind its conv work: requested there they were a
-  // memory round trip of their own on the wave every other one waits for at B1)
+  // the P1a wave also fetches the chunk's gate inputs here (consumed in P1a, behind its conv work: requested there they were
+  // a memory round trip of their own on the wave every other one waits for at B1)
   float p1_g = 0.f, p1_b = 0.f, p1_dt = 0.f, p1_A = 0.f;
   if (wave_u == P1A_WAVE) {
     const size_t tok1 = ((size_t)b * T + t0 + min(lane, nvalid - 1)) * H + h;
@@ -268,7 +267,6 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     }
   }
   auto qk_row = [&](int rr) { return FUSED ? 4 * r0 + rr : r0 + 32 * rr; };
-  auto v_row = [&](int i) { return FUSED ? 8 * vr + i : vr + 8 * i; };
   if constexpr (!FUSED) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -277,13 +275,6 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       kraw[rr] = *(const u32x4*)(k + tok * GK + 8 * oct);
       qraw[rr] = *(const u32x4*)(q + tok * GK + 8 * oct);
       braw[rr] = beta[tok];
-    }
-    if (wave_u >= 4) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = min(vr + 8 * i, nvalid - 1);
-        vraw[i] = *(const u32x4*)(v + (((size_t)b * T + t0 + row) * H + h) * GV + 8 * voct);
-      }
     }
   } else {
     const bf16_t* xb = pf.proj + (size_t)b * T * pf.ld;              // row t at xb + t * ld (32-bit element offsets: host-checked)
@@ -303,10 +294,10 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     // (the state is REQUESTED by history_load together with the run's own loads and only consumed by history: requested
     // where it is consumed it costs the workgroup that holds time 0 - the one every launch waits for - a second full
     // memory round trip, ~3,400 cycles)
-    auto history_load = [&](u32x4* s4, const bf16_t* st_in, int dch) {
+    auto history_load = [&](u32x4* s4, const bf16_t* st_in) {
       s4[0] = s4[1] = s4[2] = s4[3] = u32x4{0u, 0u, 0u, 0u};
       if (st_in != nullptr) {
-        const u32x4* sp = (const u32x4*)(st_in + ((size_t)b * H * (dch == 2 ? GV : GK) + (size_t)h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct)) * 4);
+        const u32x4* sp = (const u32x4*)(st_in + ((size_t)b * H * GK + (size_t)h * GK + 8 * oct) * 4);
         s4[0] = sp[0]; s4[1] = sp[1]; s4[2] = sp[2]; s4[3] = sp[3];
       }
     };
@@ -337,9 +328,9 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
         tail[j] = *(const u32x4*)(xb + ((unsigned int)tg * ld32 + (unsigned int)col));
       }
     };
-    auto put_state = [&](const u32x4* tail, const u32x4* hist3, bf16_t* st_out, int dch) {
+    auto put_state = [&](const u32x4* tail, const u32x4* hist3, bf16_t* st_out) {
       if (st_out == nullptr) return;
-      const int D = H * (dch == 2 ? GV : GK), d0 = h * (dch == 2 ? GV : GK) + 8 * (dch == 2 ? voct : oct);
+      const int D = H * GK, d0 = h * GK + 8 * oct;
       u32x4 row[4];
       if (T >= 4) {                                                    // (uniform) the last four inputs, as loaded
 #pragma unroll
@@ -363,65 +354,44 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       }
     };
     const bool own_state = t0 == 0;                                    // this workgroup holds time 0
-    if (wave_u < 4) {
-      u32x4 xq[7], xk[7], wq[4], wk[4];
-      const int cq = pf.col_q + h * GK + 8 * oct, ck = pf.col_k + h * GK + 8 * oct;
-      load_run(xq, 4 * r0, std::integral_constant<int, 4>{}, cq);
-      load_run(xk, 4 * r0, std::integral_constant<int, 4>{}, ck);
-      const u32x4* wqp = (const u32x4*)(pf.w[0] + ((size_t)h * GK + 8 * oct) * 4);
-      const u32x4* wkp = (const u32x4*)(pf.w[1] + ((size_t)h * GK + 8 * oct) * 4);
+    {
+      const int a = is_k ? 1 : 0;                                      // 0: q, 1: k (wave-uniform)
+      u32x4 xr[7], wt[4];
+      const int col = (is_k ? pf.col_k : pf.col_q) + h * GK + 8 * oct;
+      load_run(xr, 4 * r0, std::integral_constant<int, 4>{}, col);
+      const u32x4* wp = (const u32x4*)(pf.w[a] + ((size_t)h * GK + 8 * oct) * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { wq[i] = wqp[i]; wk[i] = wkp[i]; }
-      bf16_t bin[4];
+      for (int i = 0; i < 4; ++i) wt[i] = wp[i];
+      bf16_t bin[4] = {0, 0, 0, 0};
+      if (is_k) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int tg = min(t0 + 4 * r0 + rr, T - 1);
-        bin[rr] = xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)];
+        for (int rr = 0; rr < 4; ++rr) {
+          const int tg = min(t0 + 4 * r0 + rr, T - 1);
+          bin[rr] = xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)];
+        }
       }
       // every load of the thread is in flight before the first one is consumed (in-order return: waiting for any of them
       // waits for all issued before it)
-      u32x4 tq[4], tk[4], sq4[4], sk4[4];
+      u32x4 tl[4], st4[4];
       if (own_state && r0 == 0) {
-        tail_load(tq, cq);
-        tail_load(tk, ck);
-        history_load(sq4, pf.st_in[0], 0);
-        history_load(sk4, pf.st_in[1], 1);
+        tail_load(tl, col);
+        history_load(st4, pf.st_in[a]);
       }
+      if (is_k) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));          // beta = bf16(sigmoid(b)) (std:1293)
+        for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));     // beta = bf16(sigmoid(b)) (std:1293)
+      }
       IVL_T(tf0);
       IVL_TOUT(8, tf0 - tp0);
       if (own_state && r0 == 0) {
-        history(xq, sq4);
-        history(xk, sk4);
-        put_state(tq, xq, pf.st_out[0], 0);
-        put_state(tk, xk, pf.st_out[1], 1);
+        history(xr, st4);
+        put_state(tl, xr, pf.st_out[a]);
       }
       IVL_T(tf1);
-      conv4_silu<4>(xq, wq, qraw);
+      if (is_k) conv4_silu<4>(xr, wt, kraw);
+      else conv4_silu<4>(xr, wt, qraw);
       IVL_T(tf2);
-      conv4_silu<4>(xk, wk, kraw);
-      IVL_T(tf3);
-      IVL_TOUT(9, tf1 - tf0); IVL_TOUT(10, tf2 - tf1); IVL_TOUT(11, tf3 - tf2);
-    } else {
-      u32x4 xv[11], wv[4];
-      const int cv = pf.col_v + h * GV + 8 * voct;
-      load_run(xv, 8 * vr, std::integral_constant<int, 8>{}, cv);
-      const u32x4* wvp = (const u32x4*)(pf.w[2] + ((size_t)h * GV + 8 * voct) * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wv[i] = wvp[i];
-      IVL_T(tv0);
-      if (own_state && vr == 0) {
-        u32x4 tv[4], sv4[4];
-        tail_load(tv, cv);
-        history_load(sv4, pf.st_in[2], 2);
-        history(xv, sv4);
-        put_state(tv, xv, pf.st_out[2], 2);
-      }
-      IVL_T(tv1);
-      conv4_silu<8>(xv, wv, vraw);
-      IVL_T(tv2);
-      IVL_TOUT_AT(448, 12, tv0 - tp0); IVL_TOUT_AT(448, 13, tv1 - tv0); IVL_TOUT_AT(448, 14, tv2 - tv1);
+      IVL_TOUT(9, tf1 - tf0); IVL_TOUT(10, tf2 - tf1);
     }
   }
   // ---- P1a (one wave): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta -------------
@@ -450,40 +420,46 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
     s_beta[lane] = bv;                               // 0 for padded rows
     ((float*)(rec + R::EG))[lane] = e;
+    ((bf16_t*)(rec + R::BETA))[lane] = f2bf(bv);     // the scan's V waves scale v with it (beta is a bf16 value: exact)
     if (lane == 0) *(float*)(rec + R::EGL) = __expf(gl);
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
+  auto norm_row = [&](u32x4 xv, int row, bool ok, float* f) {        // f[0..7] = x / |x| (fp32), 0 for a padded row
+    const unsigned int xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { f[2 * c] = bflo(xw[c]); f[2 * c + 1] = bfhi(xw[c]); }
+    float rs = 1.f;
+    if (l2norm) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ss = fmaf(f[c], f[c], ss);
+      ss = row16_sum(ss);
+      rs = __builtin_amdgcn_rsqf(ss + 1e-6f);
+    }
+    rs = ok ? rs : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] *= rs;
+  };
+  auto put_k = [&](const float* f, int row, float bt) {
+    float kf[8], kb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { kf[c] = bf_round(f[c]); kb[c] = kf[c] * bt; }
+    *(u32x4*)(s_kh + row * P_LDK + 8 * oct) = pack8(kf[0], kf[1], kf[2], kf[3], kf[4], kf[5], kf[6], kf[7]);
+    *(u32x4*)(s_kb + row * P_LDK + 8 * oct) = pack8(kb[0], kb[1], kb[2], kb[3], kb[4], kb[5], kb[6], kb[7]);
+  };
 #pragma unroll
   for (int rr = 0; rr < NQK; ++rr) {
-    if (FUSED && wave_u >= 4) break;                 // fused: waves 4-7 hold v
     const int row = qk_row(rr);
     const bool ok = row < nvalid;
-    const u32x4 kv = kraw[rr], qv = qraw[rr];
-    float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
-    float qf[8] = {bflo(qv.x), bfhi(qv.x), bflo(qv.y), bfhi(qv.y), bflo(qv.z), bfhi(qv.z), bflo(qv.w), bfhi(qv.w)};
-    float rk = 1.f, rq = 1.f;
-    if (l2norm) {
-      float ks = 0.f, qs = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { ks = fmaf(kf[c], kf[c], ks); qs = fmaf(qf[c], qf[c], qs); }
-      ks = row16_sum(ks);
-      qs = row16_sum(qs);
-      rk = __builtin_amdgcn_rsqf(ks + 1e-6f);
-      rq = __builtin_amdgcn_rsqf(qs + 1e-6f);
+    float f[8];
+    if (!FUSED || is_k) {
+      norm_row(kraw[rr], row, ok, f);
+      put_k(f, row, ok ? bf2f(braw[rr]) : 0.f);
     }
-    rk = ok ? rk : 0.f;
-    rq = ok ? rq : 0.f;
-    const float bt = ok ? bf2f(braw[rr]) : 0.f;
-    float kb[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      kf[c] = bf_round(kf[c] * rk);
-      qf[c] = qf[c] * rq;
-      kb[c] = kf[c] * bt;
+    if (!FUSED || !is_k) {
+      norm_row(qraw[rr], row, ok, f);
+      *(u32x4*)(s_qh + row * P_LDK + 8 * oct) = pack8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
     }
-    *(u32x4*)(s_kh + row * P_LDK + 8 * oct) = pack8(kf[0], kf[1], kf[2], kf[3], kf[4], kf[5], kf[6], kf[7]);
-    *(u32x4*)(s_qh + row * P_LDK + 8 * oct) = pack8(qf[0], qf[1], qf[2], qf[3], qf[4], qf[5], qf[6], qf[7]);
-    *(u32x4*)(s_kb + row * P_LDK + 8 * oct) = pack8(kb[0], kb[1], kb[2], kb[3], kb[4], kb[5], kb[6], kb[7]);
   }
   IVL_T(tb1);
   IVL_TOUT(15, tb1 - tp0); IVL_TOUT_AT(448, 29, tb1 - tp0); IVL_TOUT_AT(64, 30, tb1 - tp0);
@@ -515,8 +491,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     }
   };
 
-  // ---- P2: waves 0-2: L = tril(kb kh^T, -1) -> s_L;  waves 3-5: A^T = kh qh^T -> Aqk blocks;  waves 6-7: zero
-  //          blocks + first copy-outs ---------------------------------------------------------------------------
+  // ---- P2: waves 0-2: L = tril(kb kh^T, -1) -> s_L;  waves 3-5: A^T = kh qh^T -> Aqk blocks;  waves 6-7: first copy-outs -----
   if (wave_u < 3) {
     const int mi = wave_u == 0 ? 0 : 1, ni = wave_u == 2 ? 1 : 0;       // tiles (0,0), (1,0), (1,1)
     f32x16 acc;
@@ -555,15 +530,13 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
         val[4 * a + c] = i >= j ? acc[4 * a + c] * __expf(gi - gj[c]) : 0.f;
       }
     }
-    const int pc0 = ((2 * mi + (l31 >> 4)) * 2 + nj) * 64 + hi * 16 + (l31 & 15);        // piece (block, g = hi, i)
+    const int pc0 = tri_blk(2 * mi + (l31 >> 4), nj) * 64 + hi * 16 + (l31 & 15);        // piece (block, g = hi, i)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       put_piece<F8>(rec + R::AQK, pc0 + 32 * p, val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p],
                     val[10 + 4 * p], val[11 + 4 * p]);
   } else {
-    // blocks (m < 2, s2 = 1) of Aqk lie strictly above the diagonal: zeros
     const int t2 = tid - 384;                        // 0..127
-    put_piece<F8>(rec + R::AQK, (2 * (t2 >> 6) + 1) * 64 + (t2 & 63), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int z = 0; z < 4; ++z) copy_piece(t2 + 128 * z);                 // QH pieces 0..511
   }
@@ -599,21 +572,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 #pragma unroll
     for (int z = 0; z < 6; ++z) copy_piece(512 + t2 + 256 * z);           // QH 512..1023, KDT 1024..2047
   }
-  __syncthreads();                                   // B3: k_hat / q_hat are dead from here on
+  __syncthreads();                                   // B3
   IVL_T(tp3a);
-  // bf16(beta v) row-major over the dead region (read after B7): waves 4-7 write one half of their rows here, beside the
-  // short level 1, and the other half beside level 2 -- neither phase waits for the ~200 VALU instructions of all eight rows
-  auto write_beta_v = [&](int i0) {
-#pragma unroll
-    for (int i = i0; i < i0 + 4; ++i) {
-      const int row = v_row(i);
-      const u32x4 vv = vraw[i];
-      const float bt = s_beta[row];
-      *(u32x4*)(s_vb + row * P_LDV + 8 * voct) =
-          pack8(bflo(vv.x) * bt, bfhi(vv.x) * bt, bflo(vv.y) * bt, bfhi(vv.y) * bt, bflo(vv.z) * bt, bfhi(vv.z) * bt, bflo(vv.w) * bt, bfhi(vv.w) * bt);
-    }
-  };
-  if (wave_u >= 4) write_beta_v(0);
   // level 1: X[hb][lb] = -D_hb (L[hb][lb] D_lb) for the block pairs (1,0) and (3,2); the intermediate product stays in
   //          the accumulator registers: with the contraction order k = 4g + s (lane group g, instruction s) register s
   //          of a 16x16x4 result IS the B operand of instruction s of the next product.
@@ -638,7 +598,6 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   //          P = T[0:32,0:32] and Q = T[32:64,32:64] are lower triangular: P[0][1] = Q[0][1] = 0.
   f32x4 Z = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ib = (wave_u >> 1) & 1, jb = wave_u & 1;
-  if (wave_u >= 4) write_beta_v(4);
   if (wave_u < 4) {
     f32x4 M[2];
 #pragma unroll
@@ -672,21 +631,28 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   __syncthreads();                                   // B6: T complete
   IVL_T(tp3);
 
-  // ---- P4a: Tu = Tw * e^{gamma_i - gamma_j} -> bf16, row-major LDS tile (8 elements per thread) ---------------------
+  // ---- P4a: Tu = Tw * e^{gamma_i - gamma_j} -> bf16, straight into its fragment blocks of the record (8 elements of one
+  //           row per thread = two 8-byte half pieces; the blocks strictly above the diagonal do not exist) ----------------
   {
     const int row = tid >> 3, c0 = 8 * (tid & 7);
-    const float gi = s_gam[row];
-    float tv[8];
+    const int m = row >> 4, i = row & 15, s2 = c0 >> 5, tt = c0 & 31;
+    if (s2 == 0 || m >= 2) {
+      const float gi = s_gam[row];
+      float tv[8];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const f32x4 tq = *(const f32x4*)(s_L + row * P_LDF + c0 + 4 * hh);
-      const f32x4 gj = *(const f32x4*)(s_gam + c0 + 4 * hh);
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x4 tq = *(const f32x4*)(s_L + row * P_LDF + c0 + 4 * hh);
+        const f32x4 gj = *(const f32x4*)(s_gam + c0 + 4 * hh);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tv[4 * hh + c] = row >= c0 + 4 * hh + c ? tq[c] * __expf(gi - gj[c]) : 0.f;
+        for (int c = 0; c < 4; ++c) tv[4 * hh + c] = row >= c0 + 4 * hh + c ? tq[c] * __expf(gi - gj[c]) : 0.f;
+      }
+      // times tt..tt+3 -> lane group g = (tt & 15) / 4, times tt+4..tt+7 -> g + 1; both in slots 0-3 (tt < 16) or 4-7 of a piece
+      const int gq = (tt & 15) >> 2, half = tt >> 4;
+      unsigned char* blk = rec + R::TU + tri_blk(m, s2) * 1024 + half * 8;
+      *(u32x2*)(blk + (16 * gq + i) * 16) = u32x2{pack2bf(tv[0], tv[1]), pack2bf(tv[2], tv[3])};
+      *(u32x2*)(blk + (16 * (gq + 1) + i) * 16) = u32x2{pack2bf(tv[4], tv[5]), pack2bf(tv[6], tv[7])};
     }
-    *(u32x4*)(s_tu + row * P_LDT + c0) = pack8(tv[0], tv[1], tv[2], tv[3], tv[4], tv[5], tv[6], tv[7]);
   }
-  __syncthreads();                                   // B7: Tu and beta v complete
   // ---- P4b: w^T = kb^T Tw^T  (transposed so that a lane owns a time row and 32 k-columns): wave -> 32x32 tile
   //           (time tile mi, k tile s);  Wn = -bf16(bf16(w) e^gamma_i) -> fragment blocks ---------------------------
   {
@@ -714,34 +680,6 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
                     bf_round(acc[4 * p + 3]) * negeg, bf_round(acc[8 + 4 * p]) * negeg, bf_round(acc[9 + 4 * p]) * negeg,
                     bf_round(acc[10 + 4 * p]) * negeg, bf_round(acc[11 + 4 * p]) * negeg);
   }
-  // ---- P4c: u = Tu (beta v): wave -> 32 value columns, both 32-row time tiles; a lane owns one column and, per
-  //           group of four accumulator registers, four consecutive times = one 8-byte piece of the scan's layout ---
-  {
-    f32x16 acc[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const u32x4 bfr = frag_tr32(s_vb, P_LDV, 16 * ks, 32 * wave_u, lane);       // (beta v)[time 16ks + 8hi + e][col 32w + l31]
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        if (ks > 2 * mi + 1) continue;               // Tu is lower triangular
-        const u32x4 tuf = *(const u32x4*)(s_tu + (32 * mi + l31) * P_LDT + 16 * ks + 8 * hi);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(tuf), mf(bfr), acc[mi], 0, 0, 0);
-      }
-    }
-    const int col = 32 * wave_u + l31;
-    unsigned char* ub = rec + R::U + (size_t)(col >> 4) * 2048 + (col & 15) * 8;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {                  // times 32 mi + 8 a + 4 hi + 0..3  ->  m = 2 mi + (a >> 1), g = 2 (a & 1) + hi
-        const int m = 2 * mi + (a >> 1), gg = 2 * (a & 1) + hi;
-        *(u32x2*)(ub + (4 * m + gg) * 128) = u32x2{pack2bf(acc[mi][4 * a], acc[mi][4 * a + 1]), pack2bf(acc[mi][4 * a + 2], acc[mi][4 * a + 3])};
-      }
-  }
   IVL_T(tp4);
 #ifdef IVL_TRACE
   // spread over the workgroups of the launch on the shared 100 MHz clock: first start (slot 26), last end (27), longest (28)
@@ -759,120 +697,436 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 // ==================================================================================================
 // (2) serial scan + output
 // ==================================================================================================
-// LDS: two operand images.  Image bytes [0, Rec::U) mirror the record (Wn, q_hat, Kd^T, Aqk, e^gamma); the workgroup's
-// slab of u (2 KB per pair) follows.  H1 = {Wn, q_hat, e^gamma, u slab} is read in the first half of a chunk,
-// H2 = {Kd^T, Aqk} in the second.  bf16: 65 KB per image; fp8: 37 KB.
+// LDS: two operand images, bytes [0, Rec::EG + 1024) of the record each (Wn, q_hat, Kd^T, Aqk, e^gamma / beta).  H1 = {Wn,
+// q_hat, e^gamma} is read in the first half of a chunk, H2 = {Kd^T, Aqk} in the second.  bf16: 55 KB per image; fp8: 28 KB.
+// Behind the images: the workgroup's slab of u (2 KB per pair, written by the V waves, one buffer), per pair the sb / v_new
+// exchange (6 fragment blocks), then the V waves' staging area (beta v as B-operand fragment blocks, 2 KB per pair).
 template <bool F8>
 struct Img {
-  static constexpr int U = Rec<F8>::U;
-  static constexpr int BYTES = U + 8192;
-  static constexpr int XCH = 2 * BYTES;                    // then per pair: sb (4 fragments) | v_new (2 fragments)
+  static constexpr int BYTES = Rec<F8>::EG + 1024;                                         // one operand image
   static constexpr int XCH_PAIR = 6 * Rec<F8>::BLK;
+  __host__ __device__ static constexpr int uslab(int ncw) { return 2 * BYTES; }              // u: 2 KB per pair, ONE buffer
+  __host__ __device__ static constexpr int xch(int ncw) { return uslab(ncw) + ncw * 2048; } // sb (4 fragments) | v_new (2 fragments) per pair
+  __host__ __device__ static constexpr int stg(int ncw) { return xch(ncw) + ncw * XCH_PAIR; } // beta v: 2 KB per pair
+  __host__ __device__ static constexpr int dummy(int ncw) { return stg(ncw) + ncw * 2048; }   // 256 B: landing zone of the touches
+  __host__ __device__ static constexpr int total(int ncw) { return dummy(ncw) + 256; }
 };
-__host__ __device__ constexpr int scan_lds_bytes(int ncw, bool f8) { return f8 ? Img<true>::XCH + ncw * Img<true>::XCH_PAIR : Img<false>::XCH + ncw * Img<false>::XCH_PAIR; }
+__host__ __device__ constexpr int scan_lds_bytes(int ncw, bool f8) { return f8 ? Img<true>::total(ncw) : Img<false>::total(ncw); }
 static_assert(scan_lds_bytes(4, false) <= 160 * 1024, "scan LDS budget");
 
-// LDS-DMA, four consecutive 1 KB pieces: global [gsrc + 1024 p + 16 lane] -> LDS [lds_dst + 1024 p + 16 lane], p = 0..3
+// LDS-DMA, NP consecutive 1 KB pieces: global [gsrc + 1024 p + 16 lane] -> LDS [lds_dst + 1024 p + 16 lane], p = 0..NP-1
 // (the instruction offset is added to both addresses).  gsrc and lds_dst are wave-uniform (SGPRs); hipcc does not count
 // these operations: completion is awaited with explicit counted s_waitcnt vmcnt and published by the following barrier.
-__device__ __forceinline__ void dma4(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
+template <int NP>
+__device__ __forceinline__ void dma_pieces(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
+  static_assert(NP >= 1 && NP <= 4, "pieces per issue");
   unsigned int keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
-}
-__device__ __forceinline__ void dma1(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
-  unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
+  if constexpr (NP == 4)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
+  else if constexpr (NP == 3)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
+  else if constexpr (NP == 2)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
 }
 // workgroup barrier that waits for this wave's LDS traffic only (no vector-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The SCAN_NL loader waves take the 4 KB DMA units of a half image round-robin (unit u -> loader u % SCAN_NL).  A DMA
-// instruction costs its wave ~50-100 cycles of issue time and a chunk takes 15 units = 60 instructions: with two loaders
-// (30 each) the loaders arrived last at the M barrier (state waves waited ~400 cycles per chunk there, ~240 with four).
-//   H1(ci): Wn | q_hat (contiguous: 8 units in bf16, 4 in fp8), the workgroup's u slab (NCW / 2 units), + 1 piece e^gamma (loader 0)
-//   H2(ci): Kd^T | Aqk (contiguous: 6 units in bf16, 3 in fp8)
-__host__ __device__ constexpr int h1_units(int ncw, bool f8) { return (f8 ? 4 : 8) + ncw / 2; }
-__host__ __device__ constexpr int h2_units(bool f8) { return f8 ? 3 : 6; }
+// The SCAN_NL loader waves take the DMA units (4 consecutive 1 KB pieces; the last unit of a region may be shorter) of a
+// half image round-robin (unit u -> loader u % SCAN_NL).  A DMA instruction costs its wave ~50-100 cycles of issue time: with
+// two loaders the loaders arrived last at the M barrier (state waves waited ~400 cycles per chunk there, ~240 with four).
+//   H1(ci): Wn | q_hat (contiguous: 32 pieces in bf16, 16 in fp8) + 1 piece e^gamma / beta (loader 0)
+//   H2(ci): Kd^T | Aqk (contiguous: 22 pieces in bf16, 11 in fp8)
+__host__ __device__ constexpr int h1_pieces(bool f8) { return f8 ? 16 : 32; }
+__host__ __device__ constexpr int h2_pieces(bool f8) { return f8 ? 11 : 22; }
 constexpr int SCAN_NL = 4;
-__host__ __device__ constexpr int units_of(int L, int n) { return (n - L + SCAN_NL - 1) / SCAN_NL; }   // units u < n with u % SCAN_NL == L
-__host__ __device__ constexpr int loader_n1(int L, int ncw, bool f8) {       // pieces of H1 issued by loader L
-  return 4 * units_of(L, h1_units(ncw, f8)) + (L == 0 ? 1 : 0);
+__host__ __device__ constexpr int unit_size(int u, int n) { return n - 4 * u >= 4 ? 4 : (n - 4 * u > 0 ? n - 4 * u : 0); }
+__host__ __device__ constexpr int loader_pieces(int L, int n) {               // pieces of an n-piece region issued by loader L
+  int c = 0;
+  for (int u = L; 4 * u < n; u += SCAN_NL) c += unit_size(u, n);
+  return c;
 }
-__host__ __device__ constexpr int loader_n2(int L, bool f8) { return 4 * units_of(L, h2_units(f8)); }
+__host__ __device__ constexpr int loader_n1(int L, bool f8) { return loader_pieces(L, h1_pieces(f8)) + (L == 0 ? 1 : 0); }
+__host__ __device__ constexpr int loader_n2(int L, bool f8) { return loader_pieces(L, h2_pieces(f8)); }
 
-template <int L, int NCW, bool F8>
-__device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, int slab_wg, unsigned int lane16) {
+template <int L, int NPIECES, int U = 0>
+__device__ __forceinline__ void load_region(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
+  if constexpr (4 * U < NPIECES) {
+    if constexpr (U % SCAN_NL == L) dma_pieces<unit_size(U, NPIECES)>(gsrc + U * 4096, lds_dst + (unsigned int)(U * 4096), lane16);
+    load_region<L, NPIECES, U + 1>(gsrc, lds_dst, lane16);
+  }
+}
+template <int L, bool F8>
+__device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, unsigned int lane16) {
   using R = Rec<F8>;
-  constexpr int NA = F8 ? 4 : 8;                   // units of Wn | q_hat
-#pragma unroll
-  for (int u = 0; u < NA; ++u)
-    if (u % SCAN_NL == L) dma4(rec + R::WN + u * 4096, img + (unsigned int)(R::WN + u * 4096), lane16);
-#pragma unroll
-  for (int u = 0; u < NCW / 2; ++u)
-    if ((NA + u) % SCAN_NL == L) dma4(rec + R::U + slab_wg * (NCW * 2048) + u * 4096, img + (unsigned int)(Img<F8>::U + u * 4096), lane16);
-  if (L == 0) dma1(rec + R::EG, img + (unsigned int)R::EG, lane16);
+  load_region<L, h1_pieces(F8)>(rec + R::WN, img + (unsigned int)R::WN, lane16);
+  if (L == 0) dma_pieces<1>(rec + R::EG, img + (unsigned int)R::EG, lane16);
 }
 template <int L, bool F8>
 __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int img, unsigned int lane16) {
   using R = Rec<F8>;
-#pragma unroll
-  for (int u = 0; u < h2_units(F8); ++u)
-    if (u % SCAN_NL == L) dma4(rec + R::KDT + u * 4096, img + (unsigned int)(R::KDT + u * 4096), lane16);
+  load_region<L, h2_pieces(F8)>(rec + R::KDT, img + (unsigned int)R::KDT, lane16);
 }
 
-// Barrier protocol (every wave of the workgroup executes the same sequence P, T(0), M(0), T(1), M(1), ...):
-//   P     : H1(0) has landed
+// Barrier protocol (every wave of the workgroup executes the same sequence P0, P, T(0), M(0), T(1), M(1), ...):
+//   P0    : beta v of chunk 0 is staged (V waves)
+//   P     : H1(0) has landed;  u(0) is in image 0
 //   T(ci) : H2(ci) has landed;  every wave has finished chunk ci - 1      -> H2(ci + 1) may be issued (image (ci+1) & 1)
+//           beta v of chunk ci + 1 is staged
 //   M(ci) : H1(ci + 1) has landed;  every wave has read H1(ci)            -> H1(ci + 2) may be issued (image ci & 1)
+//           u(ci + 1) is in image (ci + 1) & 1;  the staging area is free
 // so each half image is requested one whole chunk before its barrier.  vmcnt retires in issue order: "landed" = at most
 // the pieces issued AFTER the awaited half are still outstanding.
+// L2 warm-up for the V waves ("touch"): a V wave reads its value rows, beta and Tu with ordinary loads ONE chunk ahead (two
+// register sets; a deeper register pipeline does not fit), which hides an L2 hit but not a trip to HBM / the other dies'
+// L2s.  Loader 2 therefore requests one dword of every 128-byte line of the workgroup's value rows of chunk c, loader 3 of
+// Tu(c) and beta(c), five chunks ahead, as LDS-DMA into a 256-byte dummy area: two instructions per chunk and workgroup.
+struct ScanTouch {
+  const unsigned char* vrow0;                          // first byte of the workgroup's columns in row 0 of this batch's values
+  unsigned int row_bytes;                              // bytes between consecutive tokens
+  int T, t_seg0;
+  unsigned int dummy;                                  // LDS byte address of the dummy area
+};
+template <int L, bool F8>
+__device__ __forceinline__ void touch_chunk(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, int lane) {
+  using R = Rec<F8>;
+  if constexpr (L != 2 && L != 3) return;
+  c = c < nt_seg ? c : nt_seg - 1;                                 // always issued (static wait counts): re-touches the last chunk
+  unsigned int keep;
+  if constexpr (L == 2) {
+    int t = tc.t_seg0 + c * GC + lane;
+    t = t > tc.T - 1 ? tc.T - 1 : t;
+    const unsigned int off = (unsigned int)(t - tc.t_seg0) * tc.row_bytes;
+    const unsigned char* base = tc.vrow0 + (size_t)tc.t_seg0 * tc.row_bytes;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(tc.dummy), "s"(base) : "memory");
+  } else {
+    const unsigned char* base = ws_bh + (size_t)c * R::STRIDE + R::EG;
+    const unsigned int off = lane < 48 ? 1024u + 128u * (unsigned int)lane : 512u + 128u * (unsigned int)(lane & 1);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(tc.dummy), "s"(base) : "memory");
+  }
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int L, int NCW, bool F8>
-__device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, int slab_wg, unsigned int lds0, unsigned int lane16) {
-  constexpr int N1 = loader_n1(L, NCW, F8), N2 = loader_n2(L, F8);          // pieces per half image issued by this loader
-  static_assert(N1 + N2 < 64, "vmcnt immediate");
-  auto wait_le = [&](int n) {                                   // s_waitcnt vmcnt(n), n a compile-time constant per call site
-    if (n == N1 + N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1 + N2) : "memory");
-    else if (n == N1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N1) : "memory");
-    else if (n == N2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
+__device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned int lds0, unsigned int lane16, const ScanTouch& tc,
+                                            int lane) {
+  constexpr int N1 = loader_n1(L, F8), N2 = loader_n2(L, F8);               // pieces per half image issued by this loader
+  constexpr int NT = (L == 2 || L == 3) ? 1 : 0;                            // touch instructions per chunk
   auto rec = [&](int ci) { return ws_bh + (size_t)ci * Rec<F8>::STRIDE; };
   auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * Img<F8>::BYTES); };
-  load_h1<L, NCW, F8>(rec(0), img(0), slab_wg, lane16);
+  load_h1<L, F8>(rec(0), img(0), lane16);
   load_h2<L, F8>(rec(0), img(0), lane16);
-  if (nt_seg > 1) {
-    load_h1<L, NCW, F8>(rec(1), img(1), slab_wg, lane16);
-    wait_le(N1 + N2);                                           // H2(0) + H1(1) behind H1(0)
-  } else {
-    wait_le(N2);                                                // H2(0) behind H1(0)
-  }
+  if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
+  touch_chunk<L, F8>(tc, ws_bh, 3, nt_seg, lane);
+  touch_chunk<L, F8>(tc, ws_bh, 4, nt_seg, lane);
+  lds_barrier();                                               // P0
+  if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT>();                 // H1(0) has landed: H2(0), H1(1) and the touches may be in flight
+  else wait_vm<N2 + 2 * NT>();
   lds_barrier();                                               // P
   for (int ci = 0; ci < nt_seg; ++ci) {
-    if (ci + 1 < nt_seg) wait_le(N1);                           // H1(ci+1) behind H2(ci)
-    else wait_le(0);
+    if (ci + 1 < nt_seg) wait_vm<N1 + NT>();                    // H2(ci) has landed: H1(ci+1) and one touch behind it
+    else wait_vm<NT>();
     lds_barrier();                                             // T(ci)
     if (ci + 1 < nt_seg) {
       load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
-      wait_le(N2);                                             // H2(ci+1) behind H1(ci+1)
+      wait_vm<N2 + NT>();                                      // H1(ci+1) has landed: a touch and H2(ci+1) behind it
     }
     lds_barrier();                                             // M(ci)
-    if (ci + 2 < nt_seg) load_h1<L, NCW, F8>(rec(ci + 2), img(ci + 2), slab_wg, lane16);
+    if (ci + 2 < nt_seg) load_h1<L, F8>(rec(ci + 2), img(ci + 2), lane16);
+    touch_chunk<L, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
   }
+  wait_vm<0>();                                                // no LDS-DMA may outlive the wave (the dummy area belongs to the workgroup)
 }
 
-// Workgroup = NCW state waves + NCW output waves + SCAN_NL (4) loader waves; pair w owns state columns v0..v0+15.
+// ---- the value side: V waves ------------------------------------------------------------------------------------------
+// u = bf16(Tu (beta v)) does not depend on the state, so it is produced inside the scan by NCW dedicated waves that run one
+// chunk AHEAD of the state waves and touch nothing the serial chain waits for:
+//   conv phase  (between M(ci) and T(ci+1)): the V waves split the workgroup's 64 x (16 NCW) value tile of chunk ci + 2 by
+//               rows (a thread = 4 consecutive tokens x 4 channels: whole 32 / 128-byte row pieces per load), apply the causal
+//               width-4 convolution + SiLU when the call hands over the raw projection (VCONV; std:1253-1283, carry-in from /
+//               carry-out to the conv state) and the beta scaling, and stage bf16(beta v) in LDS as B-operand fragment blocks;
+//   mma phase   (between T(ci) and M(ci)): V wave p multiplies pair p's two staged blocks by the six non-zero blocks of Tu
+//               (loaded lane-linearly from the record into registers, a chunk ahead), rounds to bf16 and stores the result
+//               in the accumulator layout into the u slab of the next image - exactly where the state wave reads it.
+// All memory operations of a V wave are ordinary compiler-tracked loads (no LDS-DMA): the counted vmcnt bookkeeping of the
+// loader waves is not mixed with them.
+struct ScanV {
+  const bf16_t* v; long long ld;                       // value rows: v[(b T + t) ld + col0 + h GV + c], bf16
+  int col0;
+  const bf16_t* w;                                     // VCONV: conv taps [H GV, 1, 4] bf16
+  const bf16_t* st_in; bf16_t* st_out;                 // VCONV: conv state [B, H GV, 4] bf16 (NULL: zero history / not wanted)
+};
+
+constexpr int SCAN_NV = 4;                             // V waves per workgroup: one per 16-row time tile of the chunk
+
+template <int NCW, bool F8, bool VCONV>
+__device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* ws_bh, unsigned char* smem, int vw, int slab_wg,
+                                           int b, int h, int H, int T, int t_seg0, int nt_seg, int lane) {
+  using R = Rec<F8>;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // V wave vw owns chunk rows 16 vw .. 16 vw + 15 of the workgroup's 16 NCW columns: a thread = 4 consecutive tokens (run) x
+  // NCW channels (NP = NCW / 2 packed bf16 pairs: one 8- or 4-byte load per row), 4 runs x 16 channel groups per wave.
+  constexpr int COLS = 16 * NCW, NP = NCW / 2;
+  const int run = lane >> 4, cgp = lane & 15;
+  const int row0 = vw * 16 + 4 * run;                              // chunk row of the thread's first token
+  const int cw = NCW * cgp;                                        // first of its columns inside the workgroup's slab
+  const int chan = slab_wg * COLS + cw;                            // ... inside the head
+  unsigned char* stg = smem + Img<F8>::stg(NCW);                   // beta v as B-operand fragment blocks: (pair, s2) at 2048 pair + 1024 s2
+  unsigned char* uslab = smem + Img<F8>::uslab(NCW) + vw * 512 + lane * 8;
+  // staging address of the thread's four tokens: block s2 = vw / 2, lane group g = run, slots 0-3 (vw even) | 4-7 (vw odd)
+  unsigned char* stg_t = stg + (vw >> 1) * 1024 + (run * 16) * 16 + (vw & 1) * 8;
+
+  // Every global load of a V wave is issued at ONE point per chunk (right behind the consumption point of the previous
+  // batch) and consumed one whole chunk later: vector-memory results return in order and the compiler's wait-count
+  // bookkeeping across the loop's back edge is conservative, so a second consumption point per iteration would wait for
+  // loads that are only half a chunk old.  Two register sets: the `_n` set is the load destination, take() moves it to the
+  // working set (the moves are where the wave waits for memory) and the next batch is issued straight away.
+  // The u product is split by ROW TILES over the V waves (wave vw: time tile m = vw, all pairs): a wave needs one or two
+  // blocks of Tu instead of all six.
+  // The data of chunk c lives in register set c & 1 (the loop below is unrolled by two so that the set index is a compile-time
+  // constant): no copies between a "load" and a "working" set.
+  unsigned int xr[2][7][NP];                                       // raw rows t-3 .. t+3 of the thread's run (VCONV: 7, else the last 4)
+  u32x2 bt[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};                    // beta of the thread's four tokens (bf16)
+  u32x4 tu[2][2];                                                  // Tu blocks (vw, 0), (vw, 1); (vw < 2, 1) is zero and not loaded
+  const long long ld = sv.ld;
+  auto ld_row = [&](const bf16_t* p, unsigned int* d) {
+    if constexpr (NP == 2) { const u32x2 x = *(const u32x2*)p; d[0] = x.x; d[1] = x.y; }
+    else d[0] = *(const unsigned int*)p;
+  };
+  // row t - 3 of the thread's run in chunk 0 of the segment (may lie in front of the tensor: only dereferenced through at())
+  const int trun = t_seg0 + row0 - 3;
+  const bf16_t* vrun = sv.v + (size_t)b * T * ld + sv.col0 + h * GV + chan + (long long)trun * ld;
+  auto at = [&](int tg) { return vrun + (long long)(tg - trun) * ld; };          // the thread's channels in row tg
+  auto issue_loads = [&](int c, auto set_tag) {                    // v rows + beta + Tu of chunk c of the segment -> set S
+    constexpr int S = decltype(set_tag)::value;
+    if (c >= nt_seg) return;
+    const int tc0 = t_seg0 + c * GC;
+    if (tc0 >= 3 && tc0 + GC <= T) {                               // interior chunk (wave-uniform): no clamping
+      const bf16_t* p = vrun + (long long)c * GC * ld;
+#pragma unroll
+      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk) ld_row(p + kk * ld, xr[S][kk]);
+    } else {
+#pragma unroll
+      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk) {
+        int tg = tc0 + row0 - 3 + kk;
+        tg = tg < 0 ? 0 : (tg > T - 1 ? T - 1 : tg);
+        ld_row(at(tg), xr[S][kk]);
+      }
+    }
+    const unsigned char* rec = ws_bh + (size_t)c * R::STRIDE;
+    bt[S] = *(const u32x2*)(rec + R::BETA + row0 * 2);
+    tu[S][0] = *(const u32x4*)(rec + R::TU + tri_blk(vw, 0) * 1024 + lane * 16);
+    if (vw >= 2) tu[S][1] = *(const u32x4*)(rec + R::TU + tri_blk(vw, 1) * 1024 + lane * 16);
+  };
+  // the consumption point of a batch: every register of set S passes through an empty asm statement, so the compiler waits
+  // for the whole batch HERE (one chunk after it was issued) and treats the values as landed from then on -- the mma of
+  // the next phase must not wait again (its wait would also cover the batch issued in between)
+  auto landed = [&](auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+    for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[S][kk][p]));
+    asm volatile("" : "+v"(bt[S]));
+    asm volatile("" : "+v"(tu[S][0]));
+    if (vw >= 2) asm volatile("" : "+v"(tu[S][1]));
+  };
+  // conv taps of the thread's channel pairs (pair p = channels 2p, 2p + 1 of the thread), kept packed (bf16): unpacked per use
+  u32x4 wpk[NP];
+  if constexpr (VCONV) {
+    const u32x4* wp = (const u32x4*)(sv.w + ((size_t)h * GV + chan) * 4);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) wpk[p] = wp[p];
+  }
+  // [conv + SiLU ->] bf16 -> * beta -> bf16, four tokens x NCW channels, staged as 8-byte half pieces (four consecutive times
+  // of one column).  Same arithmetic and rounding points as ivl_short_conv_fwd / gdn_prologue_kernel followed by the beta
+  // scaling of the round-2 pre-pass.
+  auto conv_stage = [&](auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
+    const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float res[4][2];                                             // [token][channel of the pair]
+      f32x2 win[3], wf[4];
+      if constexpr (VCONV) {
+        const u32x4 w0 = wpk[p];
+        wf[0] = f32x2{bflo(w0.x), bflo(w0.z)}; wf[1] = f32x2{bfhi(w0.x), bfhi(w0.z)};
+        wf[2] = f32x2{bflo(w0.y), bflo(w0.w)}; wf[3] = f32x2{bfhi(w0.y), bfhi(w0.w)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) win[k] = f32x2{bflo(xr[S][k][p]), bfhi(xr[S][k][p])};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2 cur = f32x2{bflo(xr[S][k + 3][p]), bfhi(xr[S][k + 3][p])};
+        f32x2 o;
+        if constexpr (VCONV) {
+          f32x2 a = wf[0] * win[0];
+          a = __builtin_elementwise_fma(wf[1], win[1], a);
+          a = __builtin_elementwise_fma(wf[2], win[2], a);
+          a = __builtin_elementwise_fma(wf[3], cur, a);
+          f32x2 e = a * nl2e;
+          e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + one;
+          o = a * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+          win[0] = win[1]; win[1] = win[2]; win[2] = cur;
+          const unsigned int ob = pack2bf(o[0], o[1]);             // the conv output is a bf16 tensor in the reference
+          o = f32x2{bflo(ob), bfhi(ob)};
+        } else {
+          o = cur;
+        }
+        const float btk = (k & 1) ? bfhi(k < 2 ? bt[S].x : bt[S].y) : bflo(k < 2 ? bt[S].x : bt[S].y);
+        res[k][0] = o[0] * btk;
+        res[k][1] = o[1] * btk;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const int col = cw + 2 * p + ch;                           // column inside the slab: pair col / 16, lane j = col % 16
+        *(u32x2*)(stg_t + (col >> 4) * 2048 + (col & 15) * 16) = u32x2{pack2bf(res[0][ch], res[1][ch]), pack2bf(res[2][ch], res[3][ch])};
+      }
+    }
+  };
+  // u = bf16(Tu (beta v)), time tile vw x every pair, into the workgroup's u slab (single buffer: the state waves read u(c)
+  // right behind the barrier that follows this phase, u(c + 1) is written a whole chunk later).  All B fragments first, then
+  // all products, then the conversions: the wave shares its SIMD's matrix pipe with an output wave.
+  auto mma_u = [&](auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p0 = 0; p0 < NCW; p0 += 2) {                          // two pairs at a time (register budget of the 16-wave workgroup)
+      u32x4 bf[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        bf[p][0] = *(const u32x4*)(stg + (p0 + p) * 2048 + lane * 16);
+        if (vw >= 2) bf[p][1] = *(const u32x4*)(stg + (p0 + p) * 2048 + 1024 + lane * 16);
+      }
+      f32x4 acc[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(tu[S][0]), mf(bf[p][0]), z, 0, 0, 0);
+      if (vw >= 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(tu[S][1]), mf(bf[p][1]), acc[p], 0, 0, 0);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        *(u32x2*)(uslab + (p0 + p) * 2048) = u32x2{pack2bf(acc[p][0], acc[p][1]), pack2bf(acc[p][2], acc[p][3])};
+    }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  IVL_T(tv_0);
+  issue_loads(0, S0{});                  // chunks 0 and 1: both in flight together
+  issue_loads(1, S1{});
+  if constexpr (VCONV) {
+    // carry-in / carry-out of the conv state: the thread that holds time 0 (first segment, V wave 0, run 0) reads the old state
+    // of its channels (taps 1..3 = times -3, -2, -1) and writes the new one = the last four inputs of the sequence
+    // ([old state, x] when T < 4) -- read before written by the same thread, so st_out may alias st_in
+    if (t_seg0 == 0 && row0 == 0) {
+      const size_t st_off = ((size_t)b * H * GV + (size_t)h * GV + chan) * 4;
+      u32x4 st[NP];
+      unsigned int tl[4][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) st[p] = sv.st_in != nullptr ? *(const u32x4*)(sv.st_in + st_off + 8 * p) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int tg = T - 4 + j;
+        tg = tg < 0 ? 0 : tg;
+        ld_row(at(tg), tl[j]);
+      }
+      constexpr unsigned int HI = 0x07060302u, LO = 0x05040100u;   // (even.hi, odd.hi) | (even.lo, odd.lo) of a word pair
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        xr[0][0][p] = __builtin_amdgcn_perm(st[p].z, st[p].x, HI); // tap 1 of the pair's two channels
+        xr[0][1][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, LO); // tap 2
+        xr[0][2][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, HI); // tap 3
+      }
+      if (sv.st_out != nullptr) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          unsigned int rw[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = T + j;                                   // ext[T + j], ext = [state(4), x(T)]
+            rw[j] = (T >= 4 || e >= 4) ? tl[j][p] : (e == 1 ? xr[0][0][p] : (e == 2 ? xr[0][1][p] : xr[0][2][p]));
+          }
+          *(u32x4*)(sv.st_out + st_off + 8 * p) = u32x4{__builtin_amdgcn_perm(rw[1], rw[0], LO), __builtin_amdgcn_perm(rw[3], rw[2], LO),
+                                                        __builtin_amdgcn_perm(rw[1], rw[0], HI), __builtin_amdgcn_perm(rw[3], rw[2], HI)};
+        }
+      }
+    }
+  }
+  landed(S0{});
+  conv_stage(S0{});                      // beta v of chunk 0
+  IVL_T(tv_1);
+  lds_barrier();                         // P0
+  mma_u(S0{});                           // u(0)
+  IVL_T(tv_2);
+  lds_barrier();                         // P
+  IVL_T(tv_3);
+  landed(S1{});                          // chunk 1
+  if (nt_seg > 1) conv_stage(S1{});
+  issue_loads(2, S0{});
+  IVL_TVAR(tv_wT); IVL_TVAR(tv_wM); IVL_TVAR(tv_mma); IVL_TVAR(tv_conv); IVL_TVAR(tv_x1); IVL_TVAR(tv_x2); IVL_TVAR(tv_x3);
+  // iteration ci: [T] u(ci + 1) from set (ci + 1) & 1 [M] beta v of chunk ci + 2 from set ci & 1, then chunk ci + 3 -> set (ci + 1) & 1
+  // (whose Tu the mma of this iteration has just consumed)
+  auto body = [&](int ci, auto even_tag) {
+    constexpr int E = decltype(even_tag)::value;                   // ci & 1
+    using SA = std::integral_constant<int, E>;
+    using SB = std::integral_constant<int, 1 - E>;
+    IVL_T(ta);
+    lds_barrier();                       // T(ci): beta v of chunk ci + 1 is staged
+    IVL_T(tb);
+    if (ci + 1 < nt_seg) mma_u(SB{});    // u(ci + 1), with Tu(ci + 1)
+    IVL_T(tc);
+    lds_barrier();                       // M(ci)
+    IVL_T(td);
+    landed(SA{});                        // chunk ci + 2 (issued a whole chunk ago)
+    IVL_T(tb2);
+    if (ci + 2 < nt_seg) conv_stage(SA{});   // beta v of chunk ci + 2
+    IVL_T(tb3);
+    issue_loads(ci + 3, SB{});           // behind the conv: the loaders' H1 burst that follows M has left the vector-memory path by then
+    IVL_T(te);
+    IVL_TACC(tv_wT, tb, ta); IVL_TACC(tv_mma, tc, tb); IVL_TACC(tv_wM, td, tc); IVL_TACC(tv_conv, te, td);
+    IVL_TACC(tv_x2, tb2, td); IVL_TACC(tv_x1, tb3, tb2); IVL_TACC(tv_x3, te, tb3);
+  };
+  for (int ci = 0; ci < nt_seg; ci += 2) {
+    body(ci, S0{});
+    if (ci + 1 < nt_seg) body(ci + 1, S1{});
+  }
+#ifdef IVL_TRACE
+  if (ivl_trace_buf != nullptr && lane == 0 && vw == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    ivl_trace_buf[31] = tv_1 - tv_0; ivl_trace_buf[32] = tv_2 - tv_1; ivl_trace_buf[33] = tv_3 - tv_2;
+    ivl_trace_buf[34] = tv_wT; ivl_trace_buf[35] = tv_mma; ivl_trace_buf[36] = tv_wM; ivl_trace_buf[37] = tv_conv;
+    ivl_trace_buf[38] = tv_x1; ivl_trace_buf[39] = tv_x2; ivl_trace_buf[40] = tv_x3;
+  }
+#endif
+}
+
+// Workgroup = NCW state waves + NCW output waves + SCAN_NL (4) loader waves + NCW V waves; pair w owns state columns v0..v0+15.
 //   state wave  : S (accumulators), per chunk  sb = bf16(S) -> LDS | T | v_new = u + Wn sb -> LDS | M | S = egl S + Kd^T v_new
 //   output wave : per chunk                                         T | (q_hat sb)^T e^gamma    | M | + v_new^T Aqk^T, store o
+//   V wave      : per chunk  (one chunk ahead)                      T | u = Tu (beta v) -> image | M | beta v of the chunk after
 // A single wave issues at most one instruction per ~4-5 cycles, and a chunk needs ~290 of them per slab: split over two
 // waves of the same SIMD the serial S -> v_new -> S chain carries 32 MFMAs + the conversions only, the other 22 MFMAs, the
 // scaling and the stores run beside it.  sb / v_new cross through 6 KB of LDS per pair, ordered by the two barriers the
@@ -880,7 +1134,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
 // NCW = 2: 32 columns, twice the workgroups -- used while the grid would otherwise leave most of the chip idle.
 // fp8 (e4m3) operand variant (F8): the four A-operand matrices arrive as 512-byte blocks, the state and v_new are
 // converted to e4m3 for the products (v_mfma_f32_16x16x32_fp8_fp8: same lane layout, 8 bytes per fragment); accumulators,
-// the carried state, u and the output stay fp32 / bf16.  Half the LDS and L2 traffic of the scan.
+// the carried state, u (and the product that makes it) and the output stay fp32 / bf16.
 template <bool F8> struct FragT { typedef u32x4 type; };
 template <> struct FragT<true> { typedef u32x2 type; };
 template <bool F8>
@@ -900,15 +1154,33 @@ __device__ __forceinline__ typename FragT<F8>::type to_frag(f32x4 lo, f32x4 hi) 
   else return pack8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
 }
 
-template <int NCW, bool F8>
-__global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL)) void gdn_chunk_scan_kernel(
-    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o,
+// wave -> role: NCW = 4: state 0-3, output 4-7, loaders 8-11, V 12-15 (one of each per SIMD);
+//               NCW = 2: state 0-1, output 2-3, loaders 4-5, V 6-7, loaders 8-9, V 10-11 (waves go to the SIMDs in the cyclic
+//               order 0, 2, 1, 3: the V waves sit beside the output waves, the loaders beside the state waves)
+enum { ROLE_STATE = 0, ROLE_OUT = 1, ROLE_LOAD = 2, ROLE_V = 3 };
+template <int NCW>
+__device__ __forceinline__ void scan_role(int w, int& role, int& idx) {
+  if (w < NCW) { role = ROLE_STATE; idx = w; }
+  else if (w < 2 * NCW) { role = ROLE_OUT; idx = w - NCW; }
+  else if (NCW == 4) {
+    if (w < 12) { role = ROLE_LOAD; idx = w - 8; }
+    else { role = ROLE_V; idx = w - 12; }
+  } else {
+    const int q = (w - 4) >> 1, r = (w - 4) & 1;            // q = 0: loaders 0,1; 1: V 0,1; 2: loaders 2,3; 3: V 2,3
+    role = (q & 1) ? ROLE_V : ROLE_LOAD;
+    idx = 2 * (q >> 1) + r;
+  }
+}
+
+template <int NCW, bool F8, bool VCONV>
+__global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_scan_kernel(
+    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
     int T, int H, int t_seg0, int nt_seg, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   using R = Rec<F8>;
   using frag_t = typename FragT<F8>::type;
-  constexpr int IMG_BYTES = Img<F8>::BYTES, IMG_U = Img<F8>::U, BLK = R::BLK;
+  constexpr int IMG_BYTES = Img<F8>::BYTES, BLK = R::BLK;
 
   IVL_T(ts0);
 #ifdef IVL_TRACE
@@ -926,25 +1198,37 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL)) void gdn_chunk_scan_kerne
   const unsigned int lane16 = lane * 16;                          // DMA piece offset
   const int lanef = lane * (BLK / 64);                            // fragment offset inside a block
   const unsigned char* ws_bh = ws + (size_t)bh * nt_seg * R::STRIDE;
+  int role, ridx;
+  scan_role<NCW>(wave_u, role, ridx);
 
-  if (wave_u >= 2 * NCW) {                                      // ---- loader waves ----
+  if (role == ROLE_LOAD) {                                      // ---- loader waves ----
     static_assert(SCAN_NL == 4, "loader dispatch below");
-    if (wave_u == 2 * NCW) scan_loader<0, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
-    else if (wave_u == 2 * NCW + 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
-    else if (wave_u == 2 * NCW + 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
-    else scan_loader<3, NCW, F8>(ws_bh, nt_seg, (int)blockIdx.y, lds0, lane16);
+    ScanTouch tc;
+    tc.vrow0 = (const unsigned char*)(sv.v + (size_t)b * T * sv.ld + sv.col0 + h * GV + (int)blockIdx.y * (16 * NCW));
+    tc.row_bytes = (unsigned int)sv.ld * 2u;
+    tc.T = T; tc.t_seg0 = t_seg0;
+    tc.dummy = lds0 + (unsigned int)Img<F8>::dummy(NCW);
+    if (ridx == 0) scan_loader<0, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
+    else if (ridx == 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
+    else if (ridx == 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
+    else scan_loader<3, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
     return;
   }
-  const int pair = wave_u < NCW ? wave_u : wave_u - NCW;
+  if (role == ROLE_V) {                                         // ---- V waves ----
+    scan_vwave<NCW, F8, VCONV>(sv, ws_bh, smem, ridx, (int)blockIdx.y, b, h, H, T, t_seg0, nt_seg, lane);
+    return;
+  }
+  const int pair = ridx;
   const int v0 = (blockIdx.y * NCW + pair) * 16;                // first state column of this pair
-  unsigned char* xsb = smem + Img<F8>::XCH + pair * Img<F8>::XCH_PAIR;   // sb: 4 fragment blocks, lane-linear
-  unsigned char* xvn = xsb + 4 * BLK;                                    // v_new: 2 fragment blocks
+  unsigned char* xsb = smem + Img<F8>::xch(NCW) + pair * Img<F8>::XCH_PAIR;   // sb: 4 fragment blocks, lane-linear
+  unsigned char* xvn = xsb + 4 * BLK;                                         // v_new: 2 fragment blocks
   auto frag = [&](const unsigned char* im, int off, int idx) { return *(const frag_t*)(im + off + idx * BLK + lanef); };
 
-  if (wave_u >= NCW) {
+  if (role == ROLE_OUT) {
     // =========================== output wave ===========================
     frag_t fq[16];
     float egv[4];
+    lds_barrier();                       // P0
     lds_barrier();                       // P: H1(0) has landed
 #pragma unroll
     for (int i = 0; i < 16; ++i) fq[i] = frag(smem, R::QH, i);
@@ -960,8 +1244,8 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL)) void gdn_chunk_scan_kerne
       frag_t sb[4], fa[6];
 #pragma unroll
       for (int s = 0; s < 4; ++s) sb[s] = *(const frag_t*)(xsb + s * BLK + lanef);
-      fa[0] = frag(img, R::AQK, 0); fa[1] = frag(img, R::AQK, 2); fa[2] = frag(img, R::AQK, 4);
-      fa[3] = frag(img, R::AQK, 5); fa[4] = frag(img, R::AQK, 6); fa[5] = frag(img, R::AQK, 7);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fa[i] = frag(img, R::AQK, i);             // tri_blk order: (0,0) (1,0) (2,0) (2,1) (3,0) (3,1)
       // (q_hat S)^T: lane (g, j) register r <-> column v0 + 4g + r, time 16m + j
       f32x4 accO[4];
 #pragma unroll
@@ -1038,10 +1322,11 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL)) void gdn_chunk_scan_kerne
 #pragma unroll
     for (int i = 0; i < 16; ++i) fw[i] = frag(im, R::WN, i);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(im + IMG_U + pair * 2048 + m * 512 + lane * 8);
+    for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(smem + Img<F8>::uslab(NCW) + pair * 2048 + m * 512 + lane * 8);
     egl = *(const float*)(im + R::EGL);
   };
-  lds_barrier();                         // P: H1(0) has landed
+  lds_barrier();                         // P0
+  lds_barrier();                         // P: H1(0) has landed, u(0) is in place
   load_h1_frags(smem);
 
   for (int ci = 0; ci < nt_seg; ++ci) {
@@ -1128,6 +1413,11 @@ using namespace ivl;
 
 static inline int seg_chunks(int NT) { return NT < G_SEG_CHUNKS ? NT : G_SEG_CHUNKS; }
 
+template <int NCW, bool F8, bool VCONV>
+static void scan_set_attr() {
+  (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<NCW, F8, VCONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            scan_lds_bytes(NCW, F8));
+}
 // dynamic-LDS opt-in, once per device (hipFuncSetAttribute acts on the current device)
 static void gdn_chunk_init_device() {
   static std::once_flag once[64];
@@ -1139,10 +1429,8 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, false>, attr, P_BYTES);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false, true>, attr, P_BYTES);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, false>, attr, scan_lds_bytes(4, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2, false>, attr, scan_lds_bytes(2, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<4, true>, attr, scan_lds_bytes(4, true));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<2, true>, attr, scan_lds_bytes(2, true));
+    scan_set_attr<4, false, false>(); scan_set_attr<2, false, false>(); scan_set_attr<4, true, false>(); scan_set_attr<2, true, false>();
+    scan_set_attr<4, false, true>(); scan_set_attr<2, false, true>(); scan_set_attr<4, true, true>(); scan_set_attr<2, true, true>();
   });
 }
 
@@ -1152,6 +1440,13 @@ extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int 
   size_t bytes = (size_t)B * H * seg_chunks(NT) * Rec<false>::STRIDE;          // the fp8 records are smaller
   if (NT > G_SEG_CHUNKS) bytes += (size_t)B * H * GK * GV * sizeof(float);   // fp32 state carried between segments
   return bytes;
+}
+
+template <int NCW, bool F8, bool VCONV>
+static void scan_launch(int B, int H, hipStream_t st, const unsigned char* wsb, bf16_t* o, const ScanV& sv, const void* hin, int hin_dt,
+                        void* hout, int hout_dt, int T, int t_seg0, int nseg, float scale) {
+  hipLaunchKernelGGL((gdn_chunk_scan_kernel<NCW, F8, VCONV>), dim3(B * H, 16 / NCW), dim3(64 * (2 * NCW + SCAN_NL + SCAN_NV)), scan_lds_bytes(NCW, F8),
+                     st, wsb, o, sv, hin, hin_dt, hout, hout_dt, T, H, t_seg0, nseg, scale);
 }
 
 template <bool F8>
@@ -1165,29 +1460,36 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
 #ifdef IVL_TRACE
   if (g_scan_ncw) ncw = g_scan_ncw;
 #endif
+  // the value side of the scan: the raw projection + conv taps + conv state (fused front end) or the convolved v tensor
+  ScanV sv;
+  if (pf != nullptr) {
+    sv.v = pf->proj; sv.ld = pf->ld; sv.col0 = pf->col_v; sv.w = pf->w[2]; sv.st_in = pf->st_in[2]; sv.st_out = pf->st_out[2];
+  } else {
+    sv.v = (const bf16_t*)v; sv.ld = (long long)H * GV; sv.col0 = 0; sv.w = nullptr; sv.st_in = nullptr; sv.st_out = nullptr;
+  }
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
     const bool first = c0 == 0, last = c0 + nseg >= NT;
     if (pf != nullptr)
       hipLaunchKernelGGL((gdn_chunk_prepare_kernel<F8, true>), dim3(nseg, B * H), dim3(512), P_BYTES, st, (const bf16_t*)nullptr,
-                         (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const bf16_t*)nullptr, *pf, wsb, T, H,
-                         c0 * GC, nseg, use_qk_l2norm);
+                         (const bf16_t*)nullptr, (const float*)nullptr, (const bf16_t*)nullptr, *pf, wsb, T, H, c0 * GC, nseg,
+                         use_qk_l2norm);
     else
       hipLaunchKernelGGL((gdn_chunk_prepare_kernel<F8, false>), dim3(nseg, B * H), dim3(512), P_BYTES, st, (const bf16_t*)q,
-                         (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, PrepFused{}, wsb, T, H, c0 * GC, nseg,
-                         use_qk_l2norm);
+                         (const bf16_t*)k, g, (const bf16_t*)beta, PrepFused{}, wsb, T, H, c0 * GC, nseg, use_qk_l2norm);
     int rc = check_launch("ivl_gdn_chunk_fwd(prepare)");
     if (rc != IVL_OK) return rc;
     const void* hin = first ? h0 : (const void*)carry;
     const int hin_dt = first ? h0_dtype : IVL_F32;
     void* hout = last ? ht : (void*)carry;
     const int hout_dt = last ? ht_dtype : IVL_F32;
-    if (ncw == 2)
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<2, F8>), dim3(B * H, 8), dim3(64 * (4 + SCAN_NL)), scan_lds_bytes(2, F8), st, (const unsigned char*)wsb,
-                         (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
-    else
-      hipLaunchKernelGGL((gdn_chunk_scan_kernel<4, F8>), dim3(B * H, 4), dim3(64 * (8 + SCAN_NL)), scan_lds_bytes(4, F8), st, (const unsigned char*)wsb,
-                         (bf16_t*)o, hin, hin_dt, hout, hout_dt, T, H, c0 * GC, nseg, scale);
+    if (pf != nullptr) {
+      if (ncw == 2) scan_launch<2, F8, true>(B, H, st, wsb, (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, c0 * GC, nseg, scale);
+      else scan_launch<4, F8, true>(B, H, st, wsb, (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, c0 * GC, nseg, scale);
+    } else {
+      if (ncw == 2) scan_launch<2, F8, false>(B, H, st, wsb, (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, c0 * GC, nseg, scale);
+      else scan_launch<4, F8, false>(B, H, st, wsb, (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, c0 * GC, nseg, scale);
+    }
     rc = check_launch("ivl_gdn_chunk_fwd(scan)");
     if (rc != IVL_OK) return rc;
   }

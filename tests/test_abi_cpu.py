@@ -93,7 +93,7 @@ def test_argument_validation_returns_codes(lib):
 
 
 def test_workspace_sizes(lib):
-    per_chunk = 91136          # 56 MFMA fragment blocks of 1 KB + e^gamma block + 32 KB of u
+    per_chunk = 62464          # 54 MFMA fragment blocks of 1 KB + e^gamma / beta block + 6 blocks of Tu (u is made in the scan)
     assert lib.ivl_gdn_chunk_workspace_bytes(1, 256, 16, 128, 256) == 16 * 4 * per_chunk
     assert lib.ivl_gdn_chunk_workspace_bytes(2, 65, 3, 128, 256) == 2 * 3 * 2 * per_chunk
     # long calls are processed in 64-chunk segments: bounded workspace + fp32 state carry

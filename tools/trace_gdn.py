@@ -48,4 +48,5 @@ for it in range(3):
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
           f"| scan realtime ticks {t[25]} -> {(t[22]-t[16]) / max(t[25], 1) * 100:.0f} MHz if the tick is 100 MHz")
+    print(f"    V wave 0: conv(0) {t[31]} | P0 wait + mma(0) {t[32]} | P wait {t[33]} | per chunk: T wait {t[34]//NT} | mma {t[35]//NT} | M wait {t[36]//NT} | conv {t[37]//NT} || conv-only {t[38]//NT} take {t[39]//NT} issue {t[40]//NT}")
 lib.ivl_debug_set_trace(None)
