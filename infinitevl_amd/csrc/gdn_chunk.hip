@@ -809,6 +809,7 @@ __device__ __forceinline__ void touch_chunk(const ScanTouch& tc, const unsigned 
   if constexpr (L != 2 && L != 3) return;
   c = c < nt_seg ? c : nt_seg - 1;                                 // always issued (static wait counts): re-touches the last chunk
   unsigned int keep;
+
   if constexpr (L == 2) {
     int t = tc.t_seg0 + c * GC + lane;
     t = t > tc.T - 1 ? tc.T - 1 : t;
@@ -858,6 +859,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     touch_chunk<L, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
   }
   wait_vm<0>();                                                // no LDS-DMA may outlive the wave (the dummy area belongs to the workgroup)
+  lds_barrier();                                               // F: the state waves' transposing store tail may use the images
 }
 
 // ---- the value side: V waves ------------------------------------------------------------------------------------------
@@ -1114,6 +1116,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     body(ci, S0{});
     if (ci + 1 < nt_seg) body(ci + 1, S1{});
   }
+  lds_barrier();                         // F
 #ifdef IVL_TRACE
   if (ivl_trace_buf != nullptr && lane == 0 && vw == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
     ivl_trace_buf[31] = tv_1 - tv_0; ivl_trace_buf[32] = tv_2 - tv_1; ivl_trace_buf[33] = tv_3 - tv_2;
@@ -1284,12 +1287,22 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
       }
       orow += 4 * ostep;
     }
+    lds_barrier();                       // F
     return;
   }
 
   // =========================== state wave ===========================
   // state slab: tile t = rows 16t..16t+15, lane (g, j) register r <-> S[16t + 4g + r][v0 + j]
+  // A bf16 state crosses HBM in whole row pieces of the workgroup's columns (16-byte vectors, 32 NCW bytes per row) and is
+  // transposed through LDS: the exchange area before the first chunk, image 0 after the last one.  (An fp32 state keeps the
+  // element-wise path: its tile does not fit the exchange area.)
+  constexpr int TROW = 32 * NCW + 16;                              // bytes per tile row (+16: bank spread of the column reads)
+  static_assert(GK * TROW <= NCW * Img<F8>::XCH_PAIR || F8, "state tile must fit the exchange area");
+  constexpr bool TILE_OK = GK * TROW <= NCW * Img<F8>::XCH_PAIR;
+  const int stid = pair * 64 + lane;                               // thread index among the state waves
+  const size_t srow0 = (size_t)bh * GK * GV + (size_t)blockIdx.y * (16 * NCW);   // element offset of the workgroup's columns in row 0
   f32x4 S[8];
+  bool tiled_in = false;
   {
     const size_t base = ((size_t)bh * GK + 4 * g) * GV + v0 + j;
     if (h0 == nullptr) {
@@ -1301,6 +1314,21 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[t][r] = hp[(size_t)(16 * t + r) * GV];
+    } else if constexpr (TILE_OK) {
+      // 128 rows x (2 NCW) 16-byte pieces, 4 per thread: global -> registers -> tile (read back behind P0)
+      unsigned char* tile = smem + Img<F8>::xch(NCW);
+      u32x4 pc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = stid + 64 * NCW * i, row = idx / (2 * NCW), pq = idx % (2 * NCW);
+        pc[i] = *(const u32x4*)((const bf16_t*)h0 + srow0 + (size_t)row * GV + 8 * pq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = stid + 64 * NCW * i, row = idx / (2 * NCW), pq = idx % (2 * NCW);
+        *(u32x4*)(tile + row * TROW + 16 * pq) = pc[i];
+      }
+      tiled_in = true;
     } else {
       const bf16_t* hp = (const bf16_t*)h0 + base;
       bf16_t raw[32];
@@ -1326,7 +1354,16 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     egl = *(const float*)(im + R::EGL);
   };
   lds_barrier();                         // P0
-  lds_barrier();                         // P: H1(0) has landed, u(0) is in place
+  if constexpr (TILE_OK) {
+    if (tiled_in) {                      // (workgroup-uniform) own slab out of the tile: column 16 pair + j, rows 16t + 4g + r
+      const unsigned char* tp = smem + Img<F8>::xch(NCW) + (4 * g) * TROW + (16 * pair + j) * 2;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[t][r] = bf2f(*(const bf16_t*)(tp + (16 * t + r) * TROW));
+    }
+  }
+  lds_barrier();                         // P: H1(0) has landed, u(0) is in place; the tile has been read (the exchange area is free)
   load_h1_frags(smem);
 
   for (int ci = 0; ci < nt_seg; ++ci) {
@@ -1379,6 +1416,17 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   }
   IVL_T(ts1);
 
+  const bool tiled_out = TILE_OK && ht != nullptr && ht_dtype != IVL_F32;         // (workgroup-uniform)
+  if constexpr (TILE_OK) {
+    if (tiled_out) {                     // own slab into the tile (image 0: every operand of the last chunk has been consumed)
+      unsigned char* tp = smem + (4 * g) * TROW + (16 * pair + j) * 2;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(bf16_t*)(tp + (16 * t + r) * TROW) = f2bf(S[t][r]);
+    }
+  }
+  lds_barrier();                         // F: every wave is done with the images; the tile is complete
   if (ht != nullptr) {
     const size_t base = ((size_t)bh * GK + 4 * g) * GV + v0 + j;
     if (ht_dtype == IVL_F32) {
@@ -1387,6 +1435,12 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hp[(size_t)(16 * t + r) * GV] = S[t][r];
+    } else if constexpr (TILE_OK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = stid + 64 * NCW * i, row = idx / (2 * NCW), pq = idx % (2 * NCW);
+        *(u32x4*)((bf16_t*)ht + srow0 + (size_t)row * GV + 8 * pq) = *(const u32x4*)(smem + row * TROW + 16 * pq);
+      }
     } else {
       bf16_t* hp = (bf16_t*)ht + base;
 #pragma unroll
