@@ -1398,7 +1398,7 @@ extern "C" size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d) {
   if (T <= SWA_QT) ns = SWA_MAX_SPLIT_PACK;      // packed decode rows may use the maximum split
   // split-KV partials (+ the rotated q / k copies of the rope pre-pass: at most 2 Hq heads of bf16 rows)
   const size_t rot = T > SWA_QT ? (size_t)B * T * Hq * SWA_D * 2 * sizeof(bf16_t) : 0;
-  if (ns == 1) return 256;
+  if (ns == 1) return rot + 256;
   return (size_t)B * ns * T * Hq * (SWA_D + 2) * sizeof(float) + rot + 256;
 }
 
@@ -1467,14 +1467,18 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   const int qg = pack ? 1 : swa_qg(a->B, a->T, a->Hq);
   const bool prefill = !pack && a->T > SWA_QT;
   hipStream_t st = (hipStream_t)stream;
-  if (prefill && nsplit > 1 && p.rcos != nullptr) {
+  // Fused M-RoPE of a prefill call: with split KV every split of a q-tile would rotate the same query rows, and in a long call
+  // (one split) every q-tile would rotate the new keys it visits again (a 4096-token call over a full ring: each key tile
+  // ~16 times, through registers instead of the LDS-DMA path) -- both cases rotate ONCE in a pre-pass; only short single-split
+  // calls keep the rotation in the kernel (one launch less).
+  if (prefill && p.rcos != nullptr && (nsplit > 1 || a->T >= 4 * PF_QT)) {
     // rotate q and the call's keys once, into the workspace behind the partials (see swa_rope_prepass_kernel)
     // rounded up to 16 bytes: the pre-pass, the attention kernel and the ring append move q_rot / k_rot as 16-byte vectors
     // (B * nsplit * T * Hq * 130 floats is only 8-byte aligned for an odd row count; the +256 slack of
     // ivl_swa_workspace_bytes covers the padding)
-    const size_t n_part = (((size_t)a->B * nsplit * a->T * a->Hq * (SWA_D + 2)) * sizeof(float) + 15) & ~(size_t)15;
+    const size_t n_part = nsplit > 1 ? (((size_t)a->B * nsplit * a->T * a->Hq * (SWA_D + 2)) * sizeof(float) + 15) & ~(size_t)15 : 0;
     const size_t n_q = (size_t)a->B * a->T * a->Hq * SWA_D, n_k = (size_t)a->B * a->T * a->Hkv * SWA_D;
-    IVL_REQUIRE(a->workspace_bytes >= n_part + (n_q + n_k) * sizeof(bf16_t), IVL_ERR_WORKSPACE,
+    IVL_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= n_part + (n_q + n_k) * sizeof(bf16_t), IVL_ERR_WORKSPACE,
                 "ivl_swa_fwd: workspace %zu bytes < required %zu (rope pre-pass)", a->workspace_bytes, n_part + (n_q + n_k) * sizeof(bf16_t));
     bf16_t* q_rot = (bf16_t*)((unsigned char*)a->workspace + n_part);
     bf16_t* k_rot = q_rot + n_q;
