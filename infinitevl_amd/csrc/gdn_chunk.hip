@@ -709,7 +709,11 @@ struct Img {
   __host__ __device__ static constexpr int xch(int ncw) { return uslab(ncw) + ncw * 2048; } // sb (4 fragments) | v_new (2 fragments) per pair
   __host__ __device__ static constexpr int stg(int ncw) { return xch(ncw) + ncw * XCH_PAIR; } // beta v: 2 KB per pair
   __host__ __device__ static constexpr int dummy(int ncw) { return stg(ncw) + ncw * 2048; }   // 256 B: landing zone of the touches
-  __host__ __device__ static constexpr int total(int ncw) { return dummy(ncw) + 256; }
+  // NCW = 2 only (the LDS of the 64-column workgroup is full): the raw value rows of a chunk, t0 - 3 .. t0 + 63 (68 row slots of
+  // 64 bytes), two buffers -- fetched by the loaders' LDS-DMA instead of 28 small vector loads per chunk by the V waves
+  static constexpr int VT_ROWS = 80, VT_BYTES = VT_ROWS * 64;     // five 1 KB DMA instructions per tile
+  __host__ __device__ static constexpr int vt(int ncw) { return dummy(ncw) + 256; }
+  __host__ __device__ static constexpr int total(int ncw) { return vt(ncw) + (ncw == 2 ? 2 * VT_BYTES : 0); }
 };
 __host__ __device__ constexpr int scan_lds_bytes(int ncw, bool f8) { return f8 ? Img<true>::total(ncw) : Img<false>::total(ncw); }
 static_assert(scan_lds_bytes(4, false) <= 160 * 1024, "scan LDS budget");
@@ -784,7 +788,8 @@ __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int i
   load_region<L, h2_pieces(F8)>(rec + R::KDT, img + (unsigned int)R::KDT, lane16);
 }
 
-// Barrier protocol (every wave of the workgroup executes the same sequence P0, P, T(0), M(0), T(1), M(1), ...):
+// Barrier protocol (every wave of the workgroup executes the same sequence PA, P0, P, T(0), M(0), T(1), M(1), ..., F):
+//   PA    : the raw value tile of chunk 0 has landed (NCW = 2)
 //   P0    : beta v of chunk 0 is staged (V waves)
 //   P     : H1(0) has landed;  u(0) is in image 0
 //   T(ci) : H2(ci) has landed;  every wave has finished chunk ci - 1      -> H2(ci + 1) may be issued (image (ci+1) & 1)
@@ -802,6 +807,7 @@ struct ScanTouch {
   unsigned int row_bytes;                              // bytes between consecutive tokens
   int T, t_seg0;
   unsigned int dummy;                                  // LDS byte address of the dummy area
+  unsigned int vt;                                     // LDS byte address of the value-tile buffers (NCW = 2)
 };
 template <int L, bool F8>
 __device__ __forceinline__ void touch_chunk(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, int lane) {
@@ -824,6 +830,34 @@ __device__ __forceinline__ void touch_chunk(const ScanTouch& tc, const unsigned 
                  : "=&s"(keep) : "v"(off), "s"(tc.dummy), "s"(base) : "memory");
   }
 }
+// NCW = 2: the workgroup's raw value rows of chunk c (rows t0 - 3 .. t0 + 63, clamped into the batch; 64 bytes = four 16-byte
+// pieces per row) into tile buffer c & 1: piece i = 4 row + piece-of-row lands at byte 16 i.  Loader 2 issues pieces 0..191,
+// loader 3 the remaining 76 (+ padding that repeats the last row).
+template <int L>
+__host__ __device__ constexpr int vt_instrs() { return L == 2 ? 3 : (L == 3 ? 2 : 0); }
+template <int L, bool F8>
+__device__ __forceinline__ void load_vt(const ScanTouch& tc, int c, int nt_seg, int lane) {
+  if constexpr (vt_instrs<L>() == 0) return;
+  c = c < nt_seg ? c : nt_seg - 1;                                 // always issued (static wait counts)
+  const int tfirst = tc.t_seg0 + c * GC - 3;
+  const int tbase = tfirst < 0 ? 0 : tfirst;
+  const unsigned char* base = tc.vrow0 + (size_t)tbase * tc.row_bytes;
+  constexpr int K0 = L == 2 ? 0 : 3, K1 = L == 2 ? 3 : 5;
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const int i = 64 * k + lane;
+    int row = i >> 2;
+    row = row > 66 ? 66 : row;
+    int t = tfirst + row;
+    t = t < 0 ? 0 : (t > tc.T - 1 ? tc.T - 1 : t);
+    const unsigned int off = (unsigned int)(t - tbase) * tc.row_bytes + 16u * (unsigned int)(i & 3);
+    const unsigned int dst = tc.vt + (unsigned int)((c & 1) * Img<F8>::VT_BYTES + 1024 * k);
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt immediate");
@@ -835,29 +869,57 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
                                             int lane) {
   constexpr int N1 = loader_n1(L, F8), N2 = loader_n2(L, F8);               // pieces per half image issued by this loader
   constexpr int NT = (L == 2 || L == 3) ? 1 : 0;                            // touch instructions per chunk
+  constexpr int NV = NCW == 2 ? vt_instrs<L>() : 0;                         // value-tile instructions per chunk
   auto rec = [&](int ci) { return ws_bh + (size_t)ci * Rec<F8>::STRIDE; };
   auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * Img<F8>::BYTES); };
+  // issue order at the start: H1(0) | value tiles 0, 1 | H2(0) | H1(1) | touches of chunks 3, 4
   load_h1<L, F8>(rec(0), img(0), lane16);
+  if constexpr (NCW == 2) {
+    load_vt<L, F8>(tc, 0, nt_seg, lane);
+    load_vt<L, F8>(tc, 1, nt_seg, lane);
+  }
   load_h2<L, F8>(rec(0), img(0), lane16);
   if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
   touch_chunk<L, F8>(tc, ws_bh, 3, nt_seg, lane);
   touch_chunk<L, F8>(tc, ws_bh, 4, nt_seg, lane);
-  lds_barrier();                                               // P0
-  if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT>();                 // H1(0) has landed: H2(0), H1(1) and the touches may be in flight
-  else wait_vm<N2 + 2 * NT>();
+  if (nt_seg > 1) wait_vm<NV + N2 + N1 + 2 * NT>();            // value tile 0 has landed (and H1(0) in front of it)
+  else wait_vm<NV + N2 + 2 * NT>();
+  lds_barrier();                                               // PA
+  lds_barrier();                                               // P0: the V waves are done with tile 0
+  if constexpr (NCW == 2) load_vt<L, F8>(tc, 2, nt_seg, lane);
+  if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT + NV>();            // H1(0) and value tile 1 have landed
+  else wait_vm<N2 + 2 * NT + NV>();
   lds_barrier();                                               // P
+  IVL_TVAR(lt_vmT); IVL_TVAR(lt_wT); IVL_TVAR(lt_iss2); IVL_TVAR(lt_vmM); IVL_TVAR(lt_wM); IVL_TVAR(lt_iss1);
   for (int ci = 0; ci < nt_seg; ++ci) {
-    if (ci + 1 < nt_seg) wait_vm<N1 + NT>();                    // H2(ci) has landed: H1(ci+1) and one touch behind it
+    // H2(ci) and value tile ci + 2 have landed: only H1(ci+1) and one touch were issued behind them (ci = 0: tile 2 is the
+    // newest request of all)
+    IVL_T(l0);
+    if (NCW == 2 && ci == 0) wait_vm<0>();
+    else if (ci + 1 < nt_seg) wait_vm<N1 + NT>();
     else wait_vm<NT>();
+    IVL_T(l1);
     lds_barrier();                                             // T(ci)
-    if (ci + 1 < nt_seg) {
-      load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
-      wait_vm<N2 + NT>();                                      // H1(ci+1) has landed: a touch and H2(ci+1) behind it
-    }
+    IVL_T(l2);
+    if (ci + 1 < nt_seg) load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
+    if constexpr (NCW == 2) load_vt<L, F8>(tc, ci + 3, nt_seg, lane);
+    IVL_T(l3);
+    if (ci + 1 < nt_seg) wait_vm<N2 + NV + NT>();              // H1(ci+1) has landed: a touch, H2(ci+1) and a value tile behind it
+    IVL_T(l4);
     lds_barrier();                                             // M(ci)
+    IVL_T(l5);
+    IVL_TACC(lt_vmT, l1, l0); IVL_TACC(lt_wT, l2, l1); IVL_TACC(lt_iss2, l3, l2); IVL_TACC(lt_vmM, l4, l3); IVL_TACC(lt_wM, l5, l4);
     if (ci + 2 < nt_seg) load_h1<L, F8>(rec(ci + 2), img(ci + 2), lane16);
     touch_chunk<L, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
+    IVL_T(l6);
+    IVL_TACC(lt_iss1, l6, l5);
   }
+#ifdef IVL_TRACE
+  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    long long* tb = ivl_trace_buf + 64 + 8 * L;
+    tb[0] = lt_vmT; tb[1] = lt_wT; tb[2] = lt_iss2; tb[3] = lt_vmM; tb[4] = lt_wM; tb[5] = lt_iss1;
+  }
+#endif
   wait_vm<0>();                                                // no LDS-DMA may outlive the wave (the dummy area belongs to the workgroup)
   lds_barrier();                                               // F: the state waves' transposing store tail may use the images
 }
@@ -921,11 +983,14 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   const int trun = t_seg0 + row0 - 3;
   const bf16_t* vrun = sv.v + (size_t)b * T * ld + sv.col0 + h * GV + chan + (long long)trun * ld;
   auto at = [&](int tg) { return vrun + (long long)(tg - trun) * ld; };          // the thread's channels in row tg
+  constexpr bool VTILE = NCW == 2;                                 // value rows come from the loaders' LDS tile, not from global loads
+  const unsigned char* vtile = smem + Img<F8>::vt(NCW) + (vw * 16 + 4 * run) * 64 + cgp * 4;   // row t - 3 of the run, the thread's channel pair
   auto issue_loads = [&](int c, auto set_tag) {                    // v rows + beta + Tu of chunk c of the segment -> set S
     constexpr int S = decltype(set_tag)::value;
     if (c >= nt_seg) return;
     const int tc0 = t_seg0 + c * GC;
-    if (tc0 >= 3 && tc0 + GC <= T) {                               // interior chunk (wave-uniform): no clamping
+    if constexpr (VTILE) {
+    } else if (tc0 >= 3 && tc0 + GC <= T) {                        // interior chunk (wave-uniform): no clamping
       const bf16_t* p = vrun + (long long)c * GC * ld;
 #pragma unroll
       for (int kk = VCONV ? 0 : 3; kk < 7; ++kk) ld_row(p + kk * ld, xr[S][kk]);
@@ -947,10 +1012,12 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   // the next phase must not wait again (its wait would also cover the batch issued in between)
   auto landed = [&](auto set_tag) {
     constexpr int S = decltype(set_tag)::value;
+    if constexpr (!VTILE) {
 #pragma unroll
-    for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
+      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[S][kk][p]));
+        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[S][kk][p]));
+    }
     asm volatile("" : "+v"(bt[S]));
     asm volatile("" : "+v"(tu[S][0]));
     if (vw >= 2) asm volatile("" : "+v"(tu[S][1]));
@@ -965,9 +1032,28 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   // [conv + SiLU ->] bf16 -> * beta -> bf16, four tokens x NCW channels, staged as 8-byte half pieces (four consecutive times
   // of one column).  Same arithmetic and rounding points as ivl_short_conv_fwd / gdn_prologue_kernel followed by the beta
   // scaling of the round-2 pre-pass.
-  auto conv_stage = [&](auto set_tag) {
+  unsigned int hist[3][NP] = {};                                   // history rows of the thread that holds time 0 (conv state)
+  bool use_hist = false;
+  auto conv_stage = [&](int c, auto set_tag) {
     constexpr int S = decltype(set_tag)::value;
     const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
+    unsigned int xv[7][NP];                                        // the run's rows t-3 .. t+3
+    if constexpr (VTILE) {
+      const unsigned char* tp = vtile + (c & 1) * Img<F8>::VT_BYTES;
+#pragma unroll
+      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk) xv[kk][0] = *(const unsigned int*)(tp + kk * 64);
+      if constexpr (VCONV) {
+        if (use_hist && c == 0) {
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) xv[kk][0] = hist[kk][0];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) xv[kk][p] = xr[S][kk][p];
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       float res[4][2];                                             // [token][channel of the pair]
@@ -977,11 +1063,11 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
         wf[0] = f32x2{bflo(w0.x), bflo(w0.z)}; wf[1] = f32x2{bfhi(w0.x), bfhi(w0.z)};
         wf[2] = f32x2{bflo(w0.y), bflo(w0.w)}; wf[3] = f32x2{bfhi(w0.y), bfhi(w0.w)};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) win[k] = f32x2{bflo(xr[S][k][p]), bfhi(xr[S][k][p])};
+        for (int k = 0; k < 3; ++k) win[k] = f32x2{bflo(xv[k][p]), bfhi(xv[k][p])};
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x2 cur = f32x2{bflo(xr[S][k + 3][p]), bfhi(xr[S][k + 3][p])};
+        const f32x2 cur = f32x2{bflo(xv[k + 3][p]), bfhi(xv[k + 3][p])};
         f32x2 o;
         if constexpr (VCONV) {
           f32x2 a = wf[0] * win[0];
@@ -1057,11 +1143,13 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
         ld_row(at(tg), tl[j]);
       }
       constexpr unsigned int HI = 0x07060302u, LO = 0x05040100u;   // (even.hi, odd.hi) | (even.lo, odd.lo) of a word pair
+      use_hist = true;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        xr[0][0][p] = __builtin_amdgcn_perm(st[p].z, st[p].x, HI); // tap 1 of the pair's two channels
-        xr[0][1][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, LO); // tap 2
-        xr[0][2][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, HI); // tap 3
+        hist[0][p] = __builtin_amdgcn_perm(st[p].z, st[p].x, HI);  // tap 1 of the pair's two channels
+        hist[1][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, LO);  // tap 2
+        hist[2][p] = __builtin_amdgcn_perm(st[p].w, st[p].y, HI);  // tap 3
+        if constexpr (!VTILE) { xr[0][0][p] = hist[0][p]; xr[0][1][p] = hist[1][p]; xr[0][2][p] = hist[2][p]; }
       }
       if (sv.st_out != nullptr) {
 #pragma unroll
@@ -1070,7 +1158,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int e = T + j;                                   // ext[T + j], ext = [state(4), x(T)]
-            rw[j] = (T >= 4 || e >= 4) ? tl[j][p] : (e == 1 ? xr[0][0][p] : (e == 2 ? xr[0][1][p] : xr[0][2][p]));
+            rw[j] = (T >= 4 || e >= 4) ? tl[j][p] : (e == 1 ? hist[0][p] : (e == 2 ? hist[1][p] : hist[2][p]));
           }
           *(u32x4*)(sv.st_out + st_off + 8 * p) = u32x4{__builtin_amdgcn_perm(rw[1], rw[0], LO), __builtin_amdgcn_perm(rw[3], rw[2], LO),
                                                         __builtin_amdgcn_perm(rw[1], rw[0], HI), __builtin_amdgcn_perm(rw[3], rw[2], HI)};
@@ -1078,8 +1166,9 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
       }
     }
   }
+  lds_barrier();                         // PA: value tile 0 has landed (NCW = 2)
   landed(S0{});
-  conv_stage(S0{});                      // beta v of chunk 0
+  conv_stage(0, S0{});                   // beta v of chunk 0
   IVL_T(tv_1);
   lds_barrier();                         // P0
   mma_u(S0{});                           // u(0)
@@ -1087,7 +1176,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   lds_barrier();                         // P
   IVL_T(tv_3);
   landed(S1{});                          // chunk 1
-  if (nt_seg > 1) conv_stage(S1{});
+  if (nt_seg > 1) conv_stage(1, S1{});
   issue_loads(2, S0{});
   IVL_TVAR(tv_wT); IVL_TVAR(tv_wM); IVL_TVAR(tv_mma); IVL_TVAR(tv_conv); IVL_TVAR(tv_x1); IVL_TVAR(tv_x2); IVL_TVAR(tv_x3);
   // iteration ci: [T] u(ci + 1) from set (ci + 1) & 1 [M] beta v of chunk ci + 2 from set ci & 1, then chunk ci + 3 -> set (ci + 1) & 1
@@ -1105,7 +1194,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     IVL_T(td);
     landed(SA{});                        // chunk ci + 2 (issued a whole chunk ago)
     IVL_T(tb2);
-    if (ci + 2 < nt_seg) conv_stage(SA{});   // beta v of chunk ci + 2
+    if (ci + 2 < nt_seg) conv_stage(ci + 2, SA{});   // beta v of chunk ci + 2
     IVL_T(tb3);
     issue_loads(ci + 3, SB{});           // behind the conv: the loaders' H1 burst that follows M has left the vector-memory path by then
     IVL_T(te);
@@ -1122,6 +1211,9 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     ivl_trace_buf[31] = tv_1 - tv_0; ivl_trace_buf[32] = tv_2 - tv_1; ivl_trace_buf[33] = tv_3 - tv_2;
     ivl_trace_buf[34] = tv_wT; ivl_trace_buf[35] = tv_mma; ivl_trace_buf[36] = tv_wM; ivl_trace_buf[37] = tv_conv;
     ivl_trace_buf[38] = tv_x1; ivl_trace_buf[39] = tv_x2; ivl_trace_buf[40] = tv_x3;
+  }
+  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    ivl_trace_buf[104 + 2 * vw] = tv_wT; ivl_trace_buf[105 + 2 * vw] = tv_wM;
   }
 #endif
 }
@@ -1158,8 +1250,9 @@ __device__ __forceinline__ typename FragT<F8>::type to_frag(f32x4 lo, f32x4 hi) 
 }
 
 // wave -> role: NCW = 4: state 0-3, output 4-7, loaders 8-11, V 12-15 (one of each per SIMD);
-//               NCW = 2: state 0-1, output 2-3, loaders 4-5, V 6-7, loaders 8-9, V 10-11 (waves go to the SIMDs in the cyclic
-//               order 0, 2, 1, 3: the V waves sit beside the output waves, the loaders beside the state waves)
+//               NCW = 2: state 0-1, output 2-3, loaders 4-5, V 6-9, loaders 10-11 (waves go to the SIMDs in the cyclic order
+//               0, 2, 1, 3: every SIMD hosts one V wave -- two of them on one SIMD made the younger one the last arrival
+//               at every barrier)
 enum { ROLE_STATE = 0, ROLE_OUT = 1, ROLE_LOAD = 2, ROLE_V = 3 };
 template <int NCW>
 __device__ __forceinline__ void scan_role(int w, int& role, int& idx) {
@@ -1169,9 +1262,9 @@ __device__ __forceinline__ void scan_role(int w, int& role, int& idx) {
     if (w < 12) { role = ROLE_LOAD; idx = w - 8; }
     else { role = ROLE_V; idx = w - 12; }
   } else {
-    const int q = (w - 4) >> 1, r = (w - 4) & 1;            // q = 0: loaders 0,1; 1: V 0,1; 2: loaders 2,3; 3: V 2,3
-    role = (q & 1) ? ROLE_V : ROLE_LOAD;
-    idx = 2 * (q >> 1) + r;
+    const int q = (w - 4) >> 1, r = (w - 4) & 1;            // q = 0: loaders 0,1; 1: V 0,1; 2: V 2,3; 3: loaders 2,3
+    role = (q == 1 || q == 2) ? ROLE_V : ROLE_LOAD;
+    idx = (q == 0 || q == 1) ? r : 2 + r;
   }
 }
 
@@ -1211,6 +1304,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     tc.row_bytes = (unsigned int)sv.ld * 2u;
     tc.T = T; tc.t_seg0 = t_seg0;
     tc.dummy = lds0 + (unsigned int)Img<F8>::dummy(NCW);
+    tc.vt = lds0 + (unsigned int)Img<F8>::vt(NCW);
     if (ridx == 0) scan_loader<0, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
     else if (ridx == 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
     else if (ridx == 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
@@ -1231,6 +1325,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     // =========================== output wave ===========================
     frag_t fq[16];
     float egv[4];
+    lds_barrier();                       // PA
     lds_barrier();                       // P0
     lds_barrier();                       // P: H1(0) has landed
 #pragma unroll
@@ -1239,11 +1334,14 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     for (int m = 0; m < 4; ++m) egv[m] = *(const float*)(smem + R::EG + (16 * m + j) * 4);
     bf16_t* orow = o + (((size_t)b * T + t_seg0 + j) * H + h) * GV + v0 + 4 * g;
     const size_t ostep = (size_t)16 * H * GV;                   // 16 tokens further
+    IVL_TVAR(ot_wT); IVL_TVAR(ot_A); IVL_TVAR(ot_wM); IVL_TVAR(ot_B);
     for (int ci = 0; ci < nt_seg; ++ci) {
       const unsigned char* img = smem + (ci & 1) * IMG_BYTES;
       const unsigned char* img_next = smem + ((ci + 1) & 1) * IMG_BYTES;
       const int tc0 = t_seg0 + ci * GC;
+      IVL_T(o0);
       lds_barrier();                     // T(ci): sb(ci) published, H2(ci) landed
+      IVL_T(o1);
       frag_t sb[4], fa[6];
 #pragma unroll
       for (int s = 0; s < 4; ++s) sb[s] = *(const frag_t*)(xsb + s * BLK + lanef);
@@ -1260,7 +1358,9 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
           accO[m] = mma16<F8>(sb[s], fq[4 * m + s], accO[m]);
 #pragma unroll
       for (int m = 0; m < 4; ++m) accO[m] *= egv[m];
+      IVL_T(o2);
       lds_barrier();                     // M(ci): v_new(ci) published, H1(ci+1) landed
+      IVL_T(o3);
       frag_t vn[2];
       vn[0] = *(const frag_t*)(xvn + lanef);
       vn[1] = *(const frag_t*)(xvn + BLK + lanef);
@@ -1286,7 +1386,17 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
             *(u32x2*)(orow + m * ostep) = u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
       }
       orow += 4 * ostep;
+      IVL_T(o4);
+      IVL_TACC(ot_wT, o1, o0); IVL_TACC(ot_A, o2, o1); IVL_TACC(ot_wM, o3, o2); IVL_TACC(ot_B, o4, o3);
     }
+#ifdef IVL_TRACE
+    if (ivl_trace_buf != nullptr && lane == 0 && pair == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+      ivl_trace_buf[100] = ot_wT; ivl_trace_buf[101] = ot_A; ivl_trace_buf[102] = ot_wM; ivl_trace_buf[103] = ot_B;
+    }
+    if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+      ivl_trace_buf[112 + 2 * pair] = ot_wT; ivl_trace_buf[113 + 2 * pair] = ot_wM;
+    }
+#endif
     lds_barrier();                       // F
     return;
   }
@@ -1353,6 +1463,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(smem + Img<F8>::uslab(NCW) + pair * 2048 + m * 512 + lane * 8);
     egl = *(const float*)(im + R::EGL);
   };
+  lds_barrier();                         // PA
   lds_barrier();                         // P0
   if constexpr (TILE_OK) {
     if (tiled_in) {                      // (workgroup-uniform) own slab out of the tile: column 16 pair + j, rows 16t + 4g + r
@@ -1455,6 +1566,11 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   IVL_TOUT(25, (long long)__builtin_amdgcn_s_memrealtime() - rt0);
 #endif
   IVL_TOUT(22, ts2); IVL_TOUT(23, t_bar2); IVL_TOUT(24, t_sb);
+#ifdef IVL_TRACE
+  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    ivl_trace_buf[120 + 2 * pair] = t_bar; ivl_trace_buf[121 + 2 * pair] = t_bar2;
+  }
+#endif
 }
 
 #ifdef IVL_TRACE

@@ -17,7 +17,7 @@ q, k, v = rn(B, T, H, K), rn(B, T, H, K), rn(B, T, H, V)
 beta = torch.rand(B, T, H, device=dev, generator=g_).to(torch.bfloat16)
 g = torch.nn.functional.logsigmoid(torch.randn(B, T, H, device=dev, generator=g_))
 state = torch.randn(B, H, K, V, device=dev, generator=g_).to(torch.bfloat16)
-trace = torch.zeros(64, dtype=torch.int64, device=dev)
+trace = torch.zeros(128, dtype=torch.int64, device=dev)
 lib.ivl_debug_set_trace.argtypes = [ctypes.c_void_p]
 run = lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True,
                                          final_state_out=state)
@@ -48,5 +48,11 @@ for it in range(3):
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
           f"| scan realtime ticks {t[25]} -> {(t[22]-t[16]) / max(t[25], 1) * 100:.0f} MHz if the tick is 100 MHz")
+    for L in range(4):
+        o = 64 + 8 * L
+        print(f"    loader {L}: vmcnt wait before T {t[o]//NT} | T wait {t[o+1]//NT} | issue H2/VT {t[o+2]//NT} | vmcnt wait before M {t[o+3]//NT} | M wait {t[o+4]//NT} | issue H1/touch {t[o+5]//NT}")
+    print("    waits at T | M per chunk -- state waves:", [(t[120+2*i]//NT, t[121+2*i]//NT) for i in range(4)], " output waves:",
+          [(t[112+2*i]//NT, t[113+2*i]//NT) for i in range(4)], " V waves:", [(t[104+2*i]//NT, t[105+2*i]//NT) for i in range(4)])
+    print(f"    output wave 0: T wait {t[100]//NT} | phase A {t[101]//NT} | M wait {t[102]//NT} | phase B {t[103]//NT}")
     print(f"    V wave 0: conv(0) {t[31]} | P0 wait + mma(0) {t[32]} | P wait {t[33]} | per chunk: T wait {t[34]//NT} | mma {t[35]//NT} | M wait {t[36]//NT} | conv {t[37]//NT} || conv-only {t[38]//NT} take {t[39]//NT} issue {t[40]//NT}")
 lib.ivl_debug_set_trace(None)
