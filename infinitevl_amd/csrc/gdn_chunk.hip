@@ -713,7 +713,12 @@ struct Img {
   // 64 bytes), two buffers -- fetched by the loaders' LDS-DMA instead of 28 small vector loads per chunk by the V waves
   static constexpr int VT_ROWS = 80, VT_BYTES = VT_ROWS * 64;     // five 1 KB DMA instructions per tile
   __host__ __device__ static constexpr int vt(int ncw) { return dummy(ncw) + 256; }
-  __host__ __device__ static constexpr int total(int ncw) { return vt(ncw) + (ncw == 2 ? 2 * VT_BYTES : 0); }
+  // ... and Tu (six 1 KB blocks) and beta (64 bf16) of a chunk, two buffers each: the V waves of the 32-column workgroup issue
+  // no vector-memory instruction at all (each costs its wave ~100 cycles beside the DMA stream)
+  static constexpr int TU_BYTES = 6 * 1024, BETA_BYTES = 256;
+  __host__ __device__ static constexpr int tub(int ncw) { return vt(ncw) + 2 * VT_BYTES; }
+  __host__ __device__ static constexpr int betab(int ncw) { return tub(ncw) + 2 * TU_BYTES; }
+  __host__ __device__ static constexpr int total(int ncw) { return ncw == 2 ? betab(ncw) + 2 * BETA_BYTES : vt(ncw); }
 };
 __host__ __device__ constexpr int scan_lds_bytes(int ncw, bool f8) { return f8 ? Img<true>::total(ncw) : Img<false>::total(ncw); }
 static_assert(scan_lds_bytes(4, false) <= 160 * 1024, "scan LDS budget");
@@ -807,8 +812,9 @@ struct ScanTouch {
   unsigned int row_bytes;                              // bytes between consecutive tokens
   int T, t_seg0;
   unsigned int dummy;                                  // LDS byte address of the dummy area
-  unsigned int vt;                                     // LDS byte address of the value-tile buffers (NCW = 2)
+  unsigned int vt, tub, betab;                         // LDS byte addresses of the value-tile / Tu / beta buffers (NCW = 2)
 };
+// WHAT = 2: the value rows, 3: Tu and beta, anything else: nothing
 template <int L, bool F8>
 __device__ __forceinline__ void touch_chunk(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, int lane) {
   using R = Rec<F8>;
@@ -858,6 +864,32 @@ __device__ __forceinline__ void load_vt(const ScanTouch& tc, int c, int nt_seg, 
   }
 }
 
+// NCW = 2: Tu(c) (six 1 KB pieces: loader 1 takes three, loader 2 two, loader 3 one) and beta(c) (one dword instruction,
+// loader 3) into buffer c & 1
+template <int L>
+__host__ __device__ constexpr int tu_instrs() { return L == 1 ? 3 : (L == 2 ? 2 : (L == 3 ? 1 : 0)); }
+template <int L, bool F8>
+__device__ __forceinline__ void load_tu(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, unsigned int lane16) {
+  if constexpr (tu_instrs<L>() > 0) {
+    c = c < nt_seg ? c : nt_seg - 1;
+    constexpr int P0_ = L == 1 ? 0 : (L == 2 ? 3 : 5);
+    const unsigned char* src = ws_bh + (size_t)c * Rec<F8>::STRIDE + Rec<F8>::TU + P0_ * 1024;
+    const unsigned int dst = tc.tub + (unsigned int)((c & 1) * Img<F8>::TU_BYTES + P0_ * 1024);
+    dma_pieces<tu_instrs<L>()>(src, dst, lane16);
+  }
+}
+template <int L, bool F8>
+__device__ __forceinline__ void load_beta(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, int lane) {
+  if constexpr (L != 3) return;
+  c = c < nt_seg ? c : nt_seg - 1;
+  const unsigned char* src = ws_bh + (size_t)c * Rec<F8>::STRIDE + Rec<F8>::BETA;
+  const unsigned int dst = tc.betab + (unsigned int)((c & 1) * Img<F8>::BETA_BYTES);
+  const unsigned int off = 4u * (unsigned int)lane;
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(dst), "s"(src) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt immediate");
@@ -868,50 +900,61 @@ template <int L, int NCW, bool F8>
 __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned int lds0, unsigned int lane16, const ScanTouch& tc,
                                             int lane) {
   constexpr int N1 = loader_n1(L, F8), N2 = loader_n2(L, F8);               // pieces per half image issued by this loader
-  constexpr int NT = (L == 2 || L == 3) ? 1 : 0;                            // touch instructions per chunk
-  constexpr int NV = NCW == 2 ? vt_instrs<L>() : 0;                         // value-tile instructions per chunk
+  // NCW = 4: the V waves load their rows / Tu / beta themselves, loaders 2, 3 warm the L2 for them (one touch per chunk)
+  // NCW = 2: the loaders fetch the value tile, beta (with H2: the "T batch") and Tu (with H1: the "M batch") for real
+  constexpr bool VD = NCW == 2;
+  constexpr int TW = VD ? 0 : (L == 2 || L == 3 ? L : 0);                   // what this loader touches (2: value rows, 3: Tu / beta)
+  constexpr int NT = TW != 0 ? 1 : 0;                                       // touch instructions per chunk
+  constexpr int NVB = VD ? vt_instrs<L>() + (L == 3 ? 1 : 0) : 0;           // value tile + beta instructions per chunk
+  constexpr int NTU = VD ? tu_instrs<L>() : 0;
+  constexpr int NTB = N2 + NVB, NMB = N1 + NTU + NT;                        // T batch, M batch (full)
   auto rec = [&](int ci) { return ws_bh + (size_t)ci * Rec<F8>::STRIDE; };
   auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * Img<F8>::BYTES); };
-  // issue order at the start: H1(0) | value tiles 0, 1 | H2(0) | H1(1) | touches of chunks 3, 4
+  auto vset = [&](int c) {                                                   // value tile, beta (and Tu at the start) of chunk c
+    if constexpr (VD) { load_vt<L, F8>(tc, c, nt_seg, lane); load_beta<L, F8>(tc, ws_bh, c, nt_seg, lane); }
+  };
+  // issue order at the start: H1(0) | chunk 0: value tile, beta, Tu | chunk 1: the same | H2(0) | H1(1) | touches
   load_h1<L, F8>(rec(0), img(0), lane16);
-  if constexpr (NCW == 2) {
-    load_vt<L, F8>(tc, 0, nt_seg, lane);
-    load_vt<L, F8>(tc, 1, nt_seg, lane);
-  }
+  vset(0);
+  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
+  vset(1);
+  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
   load_h2<L, F8>(rec(0), img(0), lane16);
   if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
-  touch_chunk<L, F8>(tc, ws_bh, 3, nt_seg, lane);
-  touch_chunk<L, F8>(tc, ws_bh, 4, nt_seg, lane);
-  if (nt_seg > 1) wait_vm<NV + N2 + N1 + 2 * NT>();            // value tile 0 has landed (and H1(0) in front of it)
-  else wait_vm<NV + N2 + 2 * NT>();
+  touch_chunk<TW, F8>(tc, ws_bh, 3, nt_seg, lane);
+  touch_chunk<TW, F8>(tc, ws_bh, 4, nt_seg, lane);
+  if (nt_seg > 1) wait_vm<NVB + NTU + N2 + N1 + 2 * NT>();     // chunk 0's value tile / beta / Tu have landed (and H1(0) in front of them)
+  else wait_vm<NVB + NTU + N2 + 2 * NT>();
   lds_barrier();                                               // PA
   lds_barrier();                                               // P0: the V waves are done with tile 0
-  if constexpr (NCW == 2) load_vt<L, F8>(tc, 2, nt_seg, lane);
-  if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT + NV>();            // H1(0) and value tile 1 have landed
-  else wait_vm<N2 + 2 * NT + NV>();
+  vset(2);
+  if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT + NVB>();           // H1(0) and chunk 1's set have landed
+  else wait_vm<N2 + 2 * NT + NVB>();
   lds_barrier();                                               // P
+  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 2, nt_seg, lane16);   // Tu buffer 0 is free: u(0) has been formed
   IVL_TVAR(lt_vmT); IVL_TVAR(lt_wT); IVL_TVAR(lt_iss2); IVL_TVAR(lt_vmM); IVL_TVAR(lt_wM); IVL_TVAR(lt_iss1);
   for (int ci = 0; ci < nt_seg; ++ci) {
-    // H2(ci) and value tile ci + 2 have landed: only H1(ci+1) and one touch were issued behind them (ci = 0: tile 2 is the
-    // newest request of all)
     IVL_T(l0);
-    if (NCW == 2 && ci == 0) wait_vm<0>();
-    else if (ci + 1 < nt_seg) wait_vm<N1 + NT>();
-    else wait_vm<NT>();
+    // the T batch of this chunk (H2(ci), value tile / beta of chunk ci + 2) has landed: only the M batch issued behind it
+    // (H1(ci+1), Tu(ci+2), a touch) may be in flight; ci = 0: only Tu(2) was issued behind value tile 2
+    if (VD && ci == 0) wait_vm<NTU>();
+    else if (ci + 1 < nt_seg) wait_vm<NMB>();
+    else wait_vm<NTU + NT>();
     IVL_T(l1);
     lds_barrier();                                             // T(ci)
     IVL_T(l2);
     if (ci + 1 < nt_seg) load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
-    if constexpr (NCW == 2) load_vt<L, F8>(tc, ci + 3, nt_seg, lane);
+    vset(ci + 3);
     IVL_T(l3);
-    if (ci + 1 < nt_seg) wait_vm<N2 + NV + NT>();              // H1(ci+1) has landed: a touch, H2(ci+1) and a value tile behind it
+    if (ci + 1 < nt_seg) wait_vm<NTB + NTU + NT>();            // H1(ci+1) has landed: the rest of its M batch and the T batch behind it
     IVL_T(l4);
     lds_barrier();                                             // M(ci)
     IVL_T(l5);
-    IVL_TACC(lt_vmT, l1, l0); IVL_TACC(lt_wT, l2, l1); IVL_TACC(lt_iss2, l3, l2); IVL_TACC(lt_vmM, l4, l3); IVL_TACC(lt_wM, l5, l4);
     if (ci + 2 < nt_seg) load_h1<L, F8>(rec(ci + 2), img(ci + 2), lane16);
-    touch_chunk<L, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
+    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, ci + 3, nt_seg, lane16);
+    touch_chunk<TW, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
     IVL_T(l6);
+    IVL_TACC(lt_vmT, l1, l0); IVL_TACC(lt_wT, l2, l1); IVL_TACC(lt_iss2, l3, l2); IVL_TACC(lt_vmM, l4, l3); IVL_TACC(lt_wM, l5, l4);
     IVL_TACC(lt_iss1, l6, l5);
   }
 #ifdef IVL_TRACE
@@ -990,6 +1033,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     if (c >= nt_seg) return;
     const int tc0 = t_seg0 + c * GC;
     if constexpr (VTILE) {
+      return;                                                      // value rows, beta and Tu arrive by the loaders' LDS-DMA
     } else if (tc0 >= 3 && tc0 + GC <= T) {                        // interior chunk (wave-uniform): no clamping
       const bf16_t* p = vrun + (long long)c * GC * ld;
 #pragma unroll
@@ -1012,12 +1056,11 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   // the next phase must not wait again (its wait would also cover the batch issued in between)
   auto landed = [&](auto set_tag) {
     constexpr int S = decltype(set_tag)::value;
-    if constexpr (!VTILE) {
+    if constexpr (VTILE) return;
 #pragma unroll
-      for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
+    for (int kk = VCONV ? 0 : 3; kk < 7; ++kk)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[S][kk][p]));
-    }
+      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[S][kk][p]));
     asm volatile("" : "+v"(bt[S]));
     asm volatile("" : "+v"(tu[S][0]));
     if (vw >= 2) asm volatile("" : "+v"(tu[S][1]));
@@ -1038,7 +1081,9 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     constexpr int S = decltype(set_tag)::value;
     const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
     unsigned int xv[7][NP];                                        // the run's rows t-3 .. t+3
+    u32x2 btv = bt[S];
     if constexpr (VTILE) {
+      btv = *(const u32x2*)(smem + Img<F8>::betab(NCW) + (c & 1) * Img<F8>::BETA_BYTES + row0 * 2);
       const unsigned char* tp = vtile + (c & 1) * Img<F8>::VT_BYTES;
 #pragma unroll
       for (int kk = VCONV ? 0 : 3; kk < 7; ++kk) xv[kk][0] = *(const unsigned int*)(tp + kk * 64);
@@ -1083,7 +1128,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
         } else {
           o = cur;
         }
-        const float btk = (k & 1) ? bfhi(k < 2 ? bt[S].x : bt[S].y) : bflo(k < 2 ? bt[S].x : bt[S].y);
+        const float btk = (k & 1) ? bfhi(k < 2 ? btv.x : btv.y) : bflo(k < 2 ? btv.x : btv.y);
         res[k][0] = o[0] * btk;
         res[k][1] = o[1] * btk;
       }
@@ -1097,9 +1142,15 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   // u = bf16(Tu (beta v)), time tile vw x every pair, into the workgroup's u slab (single buffer: the state waves read u(c)
   // right behind the barrier that follows this phase, u(c + 1) is written a whole chunk later).  All B fragments first, then
   // all products, then the conversions: the wave shares its SIMD's matrix pipe with an output wave.
-  auto mma_u = [&](auto set_tag) {
+  auto mma_u = [&](int c, auto set_tag) {
     constexpr int S = decltype(set_tag)::value;
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 t0 = tu[S][0], t1 = tu[S][1];
+    if constexpr (VTILE) {
+      const unsigned char* tb = smem + Img<F8>::tub(NCW) + (c & 1) * Img<F8>::TU_BYTES + lane * 16;
+      t0 = *(const u32x4*)(tb + tri_blk(vw, 0) * 1024);
+      if (vw >= 2) t1 = *(const u32x4*)(tb + tri_blk(vw, 1) * 1024);
+    }
 #pragma unroll
     for (int p0 = 0; p0 < NCW; p0 += 2) {                          // two pairs at a time (register budget of the 16-wave workgroup)
       u32x4 bf[2][2];
@@ -1110,10 +1161,10 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
       }
       f32x4 acc[2];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(tu[S][0]), mf(bf[p][0]), z, 0, 0, 0);
+      for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(t0), mf(bf[p][0]), z, 0, 0, 0);
       if (vw >= 2) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(tu[S][1]), mf(bf[p][1]), acc[p], 0, 0, 0);
+        for (int p = 0; p < 2; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf(t1), mf(bf[p][1]), acc[p], 0, 0, 0);
       }
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -1171,7 +1222,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   conv_stage(0, S0{});                   // beta v of chunk 0
   IVL_T(tv_1);
   lds_barrier();                         // P0
-  mma_u(S0{});                           // u(0)
+  mma_u(0, S0{});                        // u(0)
   IVL_T(tv_2);
   lds_barrier();                         // P
   IVL_T(tv_3);
@@ -1188,7 +1239,7 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
     IVL_T(ta);
     lds_barrier();                       // T(ci): beta v of chunk ci + 1 is staged
     IVL_T(tb);
-    if (ci + 1 < nt_seg) mma_u(SB{});    // u(ci + 1), with Tu(ci + 1)
+    if (ci + 1 < nt_seg) mma_u(ci + 1, SB{});    // u(ci + 1), with Tu(ci + 1)
     IVL_T(tc);
     lds_barrier();                       // M(ci)
     IVL_T(td);
@@ -1305,6 +1356,8 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     tc.T = T; tc.t_seg0 = t_seg0;
     tc.dummy = lds0 + (unsigned int)Img<F8>::dummy(NCW);
     tc.vt = lds0 + (unsigned int)Img<F8>::vt(NCW);
+    tc.tub = lds0 + (unsigned int)Img<F8>::tub(NCW);
+    tc.betab = lds0 + (unsigned int)Img<F8>::betab(NCW);
     if (ridx == 0) scan_loader<0, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
     else if (ridx == 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
     else if (ridx == 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
