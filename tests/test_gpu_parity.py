@@ -1517,7 +1517,11 @@ def test_full_attention_layer_with_dynamic_cache_equals_one_causal_call():
 
 
 @pytest.mark.parametrize("B,T,hist,st_dtype", [(1, 256, True, torch.bfloat16), (2, 130, False, torch.float32), (1, 65, True, torch.float32),
-                                              (1, 3, True, torch.bfloat16), (1, 1000, True, torch.bfloat16)])
+                                              (1, 3, True, torch.bfloat16), (1, 1000, True, torch.bfloat16),
+                                              # 64-column scan workgroups (B H > 32: the V waves load their rows themselves)
+                                              (3, 200, True, torch.bfloat16), (4, 70, False, torch.float32),
+                                              # two workspace segments (68 chunks): value rows / history of a segment that does not start at 0
+                                              (1, 4300, True, torch.bfloat16)])
 def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
     """the pre-pass that applies the three short convs (+SiLU, carry-in / carry-out) and the gate math
     itself (ivl_gdn_chunk_fused_fwd) must equal ivl_gdn_prologue_fwd followed by ivl_gdn_chunk_fwd bit for bit: outputs,
