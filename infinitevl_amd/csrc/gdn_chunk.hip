@@ -913,18 +913,19 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   auto vset = [&](int c) {                                                   // value tile, beta (and Tu at the start) of chunk c
     if constexpr (VD) { load_vt<L, F8>(tc, c, nt_seg, lane); load_beta<L, F8>(tc, ws_bh, c, nt_seg, lane); }
   };
-  // issue order at the start: H1(0) | chunk 0: value tile, beta, Tu | chunk 1: the same | H2(0) | H1(1) | touches
-  load_h1<L, F8>(rec(0), img(0), lane16);
+  // issue order at the start: chunk 0's value tile, beta, Tu (the V waves' conversion + product of chunk 0 stand between their
+  // arrival and the first chunk step) | H1(0) | chunk 1's set | H2(0) | H1(1) | touches
   vset(0);
   if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
+  load_h1<L, F8>(rec(0), img(0), lane16);
   vset(1);
   if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
   load_h2<L, F8>(rec(0), img(0), lane16);
   if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
   touch_chunk<TW, F8>(tc, ws_bh, 3, nt_seg, lane);
   touch_chunk<TW, F8>(tc, ws_bh, 4, nt_seg, lane);
-  if (nt_seg > 1) wait_vm<NVB + NTU + N2 + N1 + 2 * NT>();     // chunk 0's value tile / beta / Tu have landed (and H1(0) in front of them)
-  else wait_vm<NVB + NTU + N2 + 2 * NT>();
+  if (nt_seg > 1) wait_vm<N1 + NVB + NTU + N2 + N1 + 2 * NT>();   // chunk 0's value tile / beta / Tu have landed
+  else wait_vm<N1 + NVB + NTU + N2 + 2 * NT>();
   lds_barrier();                                               // PA
   lds_barrier();                                               // P0: the V waves are done with tile 0
   vset(2);
