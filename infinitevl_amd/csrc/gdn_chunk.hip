@@ -1457,9 +1457,9 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
 
   // =========================== state wave ===========================
   // state slab: tile t = rows 16t..16t+15, lane (g, j) register r <-> S[16t + 4g + r][v0 + j]
-  // A bf16 state crosses HBM in whole row pieces of the workgroup's columns (16-byte vectors, 32 NCW bytes per row) and is
-  // transposed through LDS: the exchange area before the first chunk, image 0 after the last one.  (An fp32 state keeps the
-  // element-wise path: its tile does not fit the exchange area.)
+  // A bf16 initial state arrives in whole row pieces of the workgroup's columns (16-byte vectors, 32 NCW bytes per row) and is
+  // transposed through LDS (the exchange area, free before the first chunk).  (An fp32 state keeps the element-wise path: its
+  // tile does not fit the exchange area.)
   constexpr int TROW = 32 * NCW + 16;                              // bytes per tile row (+16: bank spread of the column reads)
   static_assert(GK * TROW <= NCW * Img<F8>::XCH_PAIR || F8, "state tile must fit the exchange area");
   constexpr bool TILE_OK = GK * TROW <= NCW * Img<F8>::XCH_PAIR;
@@ -1581,17 +1581,8 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   }
   IVL_T(ts1);
 
-  const bool tiled_out = TILE_OK && ht != nullptr && ht_dtype != IVL_F32;         // (workgroup-uniform)
-  if constexpr (TILE_OK) {
-    if (tiled_out) {                     // own slab into the tile (image 0: every operand of the last chunk has been consumed)
-      unsigned char* tp = smem + (4 * g) * TROW + (16 * pair + j) * 2;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *(bf16_t*)(tp + (16 * t + r) * TROW) = f2bf(S[t][r]);
-    }
-  }
-  lds_barrier();                         // F: every wave is done with the images; the tile is complete
+  // the final state leaves element-wise (an LDS-transposed store was measured: the workgroup barrier it needs in front of the
+  // row stores -- every wave must be done with the images -- costs more than the 32 two-byte stores per lane save)
   if (ht != nullptr) {
     const size_t base = ((size_t)bh * GK + 4 * g) * GV + v0 + j;
     if (ht_dtype == IVL_F32) {
@@ -1600,12 +1591,6 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hp[(size_t)(16 * t + r) * GV] = S[t][r];
-    } else if constexpr (TILE_OK) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = stid + 64 * NCW * i, row = idx / (2 * NCW), pq = idx % (2 * NCW);
-        *(u32x4*)((bf16_t*)ht + srow0 + (size_t)row * GV + 8 * pq) = *(const u32x4*)(smem + row * TROW + 16 * pq);
-      }
     } else {
       bf16_t* hp = (bf16_t*)ht + base;
 #pragma unroll
@@ -1614,6 +1599,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
         for (int r = 0; r < 4; ++r) hp[(size_t)(16 * t + r) * GV] = f2bf(S[t][r]);
     }
   }
+  lds_barrier();                         // F (matches the other roles' count)
   IVL_T(ts2);
   IVL_TOUT(16, ts0); IVL_TOUT(17, t_bar); IVL_TOUT(18, t_h1); IVL_TOUT(19, t_h2); IVL_TOUT(20, ts1 - ts0); IVL_TOUT(21, ts2 - ts1);
 #ifdef IVL_TRACE
