@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 5
+#define IVL_ABI_VERSION 6
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -95,13 +95,20 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  * col_a / col_b = first column of the a / b gate inputs ([H]); conv taps wq / wk / wv bf16 [D, 1, 4]; conv states
  * [B, D, 4] bf16 (in: NULL = zero history; out: NULL = not wanted; out may alias in).  The rest as ivl_gdn_chunk_fwd
  * (q/k l2norm always on, as the reference calls it).
+ * `sync` (optional, NULL = always two launches): IVL_GDN_SYNC_BYTES of device memory, 16-byte aligned, that the CALLER
+ *   zeroed once (hipMemset) before its first use and that nothing but this entry point has written since; one area per
+ *   stream of concurrent calls.  With it, calls whose pre-pass and scan workgroups all fit the chip at once (B*H*(T/64 + 8)
+ *   <= 256 and B*H <= 32: the 256-token streaming step) run as ONE launch: the scan workgroups start beside the pre-pass
+ *   workgroups and wait on flags in this area, which the launch itself clears again (all-zero between launches, so the
+ *   call is replayable from a hipGraph).  Results are bit-identical to the two-launch form.
  * ------------------------------------------------------------------------------------------- */
+#define IVL_GDN_SYNC_BYTES 4096
 IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
                             const void* wq, const void* wk, const void* wv, const void* sq_in, const void* sk_in,
                             const void* sv_in, void* sq_out, void* sk_out, void* sv_out, const float* A_log,
                             const float* dt_bias, void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype, int B,
                             int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            size_t workspace_bytes, void* sync, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gate math: beta = sigmoid(b) (bf16), g = -exp(A_log) * softplus(a + dt_bias) (fp32).

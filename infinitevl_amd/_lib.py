@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 
 IVL_BF16, IVL_F32, IVL_FP8_E4M3 = 0, 2, 3
 IVL_OK = 0
+IVL_GDN_SYNC_BYTES = 4096
 IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
 
 EXPORTED_SYMBOLS = (
@@ -80,7 +81,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_chunk_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, i, vp, sz, vp]
     lib.ivl_gdn_chunk_fused_fwd.restype = i
     lib.ivl_gdn_chunk_fused_fwd.argtypes = ([vp, c_int64, i, i, i, i, i] + [vp] * 9 + [vp, vp, vp, vp, i, vp, i] +
-                                            [i, i, i, i, i, i, f, i, vp, sz, vp])
+                                            [i, i, i, i, i, i, f, i, vp, sz, vp, vp])
     lib.ivl_rope_tables_fwd.restype = i
     lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, vp]
     lib.ivl_vision_attn_workspace_bytes.restype = sz

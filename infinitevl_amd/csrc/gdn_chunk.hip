@@ -38,6 +38,16 @@
 
 namespace ivl {
 IVL_TRACE_DECL(gdn)
+// scan timeline slots: thread 0 of the FIRST scan workgroup (block (0, 0) of the scan launch; a later block of the single launch)
+#ifdef IVL_TRACE
+#define IVL_TOUT_WG(first, slot, value)                                             \
+  do {                                                                              \
+    long long* tb_ = ivl_trace_buf;                                                 \
+    if (tb_ != nullptr && threadIdx.x == 0 && (first)) tb_[slot] = (long long)(value); \
+  } while (0)
+#else
+#define IVL_TOUT_WG(first, slot, value) ((void)0)
+#endif
 
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -92,11 +102,33 @@ __device__ __forceinline__ unsigned int pack4_fp8(float a, float b, float c, flo
   return (unsigned int)r;
 }
 // piece `idx` (lane-linear position inside a sequence of fragment blocks) <- eight consecutive contraction slots
-template <bool F8>
+// Record stores.  DEV (single-launch form: the record is read by other workgroups of the SAME launch, possibly through another
+// die's L2): device-scope stores (sc1: written through this die's write-back L2 to the level every die sees) -- hipcc does not
+// count them, the pre-pass drains them with an explicit s_waitcnt vmcnt(0) before it raises its flag.  A write-back of the L2
+// (the release fence the memory model prescribes) walks the whole cache: ~8 us, more than the second launch it would save.
+template <bool DEV> __device__ __forceinline__ void rec_st(void* p, u32x4 v) {
+  // s_nop: a vector-memory store of more than 64 bits must not be followed at once by a VALU write of its data registers
+  // (the compiler's hazard recognizer does not look inside an asm statement)
+  if constexpr (DEV) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *(u32x4*)p = v;
+}
+template <bool DEV> __device__ __forceinline__ void rec_st(void* p, u32x2 v) {
+  if constexpr (DEV) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *(u32x2*)p = v;
+}
+template <bool DEV> __device__ __forceinline__ void rec_st(void* p, float v) {
+  if constexpr (DEV) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *(float*)p = v;
+}
+template <bool DEV> __device__ __forceinline__ void rec_st(void* p, bf16_t v) {
+  if constexpr (DEV) asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((unsigned int)v) : "memory");
+  else *(bf16_t*)p = v;
+}
+template <bool F8, bool DEV>
 __device__ __forceinline__ void put_piece(unsigned char* base, int idx, float a0, float a1, float a2, float a3, float a4, float a5,
                                           float a6, float a7) {
-  if (F8) *(u32x2*)(base + idx * 8) = u32x2{pack4_fp8(a0, a1, a2, a3), pack4_fp8(a4, a5, a6, a7)};
-  else *(u32x4*)(base + idx * 16) = pack8(a0, a1, a2, a3, a4, a5, a6, a7);
+  if (F8) rec_st<DEV>(base + idx * 8, u32x2{pack4_fp8(a0, a1, a2, a3), pack4_fp8(a4, a5, a6, a7)});
+  else rec_st<DEV>(base + idx * 16, pack8(a0, a1, a2, a3, a4, a5, a6, a7));
 }
 
 // ==================================================================================================
@@ -205,11 +237,14 @@ __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x
   }
 }
 
-template <bool F8, bool FUSED>
-__global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
+// The pre-pass of one (chunk ci, batch*head bh) by the first 512 threads of the workgroup.  `done` (single-launch form only):
+// the word the scan workgroups of this head poll -- set once the whole record is visible device-wide.
+template <bool F8, bool FUSED, bool DEV>
+__device__ __forceinline__ void gdn_chunk_prepare_body(
+    unsigned char* smem, const int ci, const int bh,
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
-    const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bf16_t* __restrict__ beta, const PrepFused& pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm,
+    unsigned int* done) {
   using R = Rec<F8>;
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
@@ -228,9 +263,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int l31 = lane & 31, hi = lane >> 5;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int ci = blockIdx.x;                  // chunk within the segment
-  const int bh = blockIdx.y;
-  const int b = bh / H, h = bh % H;
+  const int b = bh / H, h = bh % H;            // ci = chunk within the segment
   const int t0 = t_seg0 + ci * GC;            // first token of the chunk
   const int nvalid = min(GC, T - t0);
   unsigned char* rec = ws + ((size_t)bh * nt_seg + ci) * R::STRIDE;
@@ -419,9 +452,9 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     s_eg[lane] = e;
     s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
     s_beta[lane] = bv;                               // 0 for padded rows
-    ((float*)(rec + R::EG))[lane] = e;
-    ((bf16_t*)(rec + R::BETA))[lane] = f2bf(bv);     // the scan's V waves scale v with it (beta is a bf16 value: exact)
-    if (lane == 0) *(float*)(rec + R::EGL) = __expf(gl);
+    rec_st<DEV>((float*)(rec + R::EG) + lane, e);
+    rec_st<DEV>((bf16_t*)(rec + R::BETA) + lane, f2bf(bv));     // the scan's V waves scale v with it (beta is a bf16 value: exact)
+    if (lane == 0) rec_st<DEV>(rec + R::EGL, __expf(gl));
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
   auto norm_row = [&](u32x4 xv, int row, bool ok, float* f) {        // f[0..7] = x / |x| (fp32), 0 for a padded row
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       const int blk = idx >> 6, m = blk >> 2, s = blk & 3;
       const bf16_t* src = s_qh + (16 * m + i) * P_LDK + 32 * s + 4 * gg;
       const u32x2 lo = *(const u32x2*)src, hi2 = *(const u32x2*)(src + 16);
-      put_piece<F8>(rec + R::QH, idx, bflo(lo.x), bfhi(lo.x), bflo(lo.y), bfhi(lo.y), bflo(hi2.x), bfhi(hi2.x), bflo(hi2.y), bfhi(hi2.y));
+      put_piece<F8, DEV>(rec + R::QH, idx, bflo(lo.x), bfhi(lo.x), bflo(lo.y), bfhi(lo.y), bflo(hi2.x), bfhi(hi2.x), bflo(hi2.y), bfhi(hi2.y));
     } else {
       const int id2 = idx - 1024, blk = id2 >> 6, t = blk >> 1, s2 = blk & 1;
       const int time0 = 32 * s2 + 4 * gg;
@@ -486,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       u32x2 w0, w1;
       __builtin_memcpy(&w0, &a0, 8);
       __builtin_memcpy(&w1, &a1, 8);
-      put_piece<F8>(rec + R::KDT, id2, bflo(w0.x) * d0[0], bfhi(w0.x) * d0[1], bflo(w0.y) * d0[2], bfhi(w0.y) * d0[3],
+      put_piece<F8, DEV>(rec + R::KDT, id2, bflo(w0.x) * d0[0], bfhi(w0.x) * d0[1], bflo(w0.y) * d0[2], bfhi(w0.y) * d0[3],
                     bflo(w1.x) * d1[0], bfhi(w1.x) * d1[1], bflo(w1.y) * d1[2], bfhi(w1.y) * d1[3]);
     }
   };
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const int pc0 = tri_blk(2 * mi + (l31 >> 4), nj) * 64 + hi * 16 + (l31 & 15);        // piece (block, g = hi, i)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      put_piece<F8>(rec + R::AQK, pc0 + 32 * p, val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p],
+      put_piece<F8, DEV>(rec + R::AQK, pc0 + 32 * p, val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p],
                     val[10 + 4 * p], val[11 + 4 * p]);
   } else {
     const int t2 = tid - 384;                        // 0..127
@@ -649,8 +682,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
       // times tt..tt+3 -> lane group g = (tt & 15) / 4, times tt+4..tt+7 -> g + 1; both in slots 0-3 (tt < 16) or 4-7 of a piece
       const int gq = (tt & 15) >> 2, half = tt >> 4;
       unsigned char* blk = rec + R::TU + tri_blk(m, s2) * 1024 + half * 8;
-      *(u32x2*)(blk + (16 * gq + i) * 16) = u32x2{pack2bf(tv[0], tv[1]), pack2bf(tv[2], tv[3])};
-      *(u32x2*)(blk + (16 * (gq + 1) + i) * 16) = u32x2{pack2bf(tv[4], tv[5]), pack2bf(tv[6], tv[7])};
+      rec_st<DEV>(blk + (16 * gq + i) * 16, u32x2{pack2bf(tv[0], tv[1]), pack2bf(tv[2], tv[3])});
+      rec_st<DEV>(blk + (16 * (gq + 1) + i) * 16, u32x2{pack2bf(tv[4], tv[5]), pack2bf(tv[6], tv[7])});
     }
   }
   // ---- P4b: w^T = kb^T Tw^T  (transposed so that a lane owns a time row and 32 k-columns): wave -> 32x32 tile
@@ -676,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const int pc0 = ((2 * mi + (l31 >> 4)) * 4 + s) * 64 + hi * 16 + (l31 & 15);
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      put_piece<F8>(rec + R::WN, pc0 + 32 * p, bf_round(acc[4 * p]) * negeg, bf_round(acc[4 * p + 1]) * negeg, bf_round(acc[4 * p + 2]) * negeg,
+      put_piece<F8, DEV>(rec + R::WN, pc0 + 32 * p, bf_round(acc[4 * p]) * negeg, bf_round(acc[4 * p + 1]) * negeg, bf_round(acc[4 * p + 2]) * negeg,
                     bf_round(acc[4 * p + 3]) * negeg, bf_round(acc[8 + 4 * p]) * negeg, bf_round(acc[9 + 4 * p]) * negeg,
                     bf_round(acc[10 + 4 * p]) * negeg, bf_round(acc[11 + 4 * p]) * negeg);
   }
@@ -692,6 +725,20 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
 #endif
   IVL_TOUT(0, tp0); IVL_TOUT(1, tp1 - tp0); IVL_TOUT(2, tp2 - tp1); IVL_TOUT(3, tp3a - tp2); IVL_TOUT(4, tp3b - tp3a);
   IVL_TOUT(5, tp3 - tp3b); IVL_TOUT(6, tp4 - tp3); IVL_TOUT(7, tp4);
+  if constexpr (DEV) {
+    // publish: every thread's (device-scope) record stores have been acknowledged, then one thread raises the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool F8, bool FUSED>
+__global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
+    const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  gdn_chunk_prepare_body<F8, FUSED, false>(smem, (int)blockIdx.x, (int)blockIdx.y, q, k, g, beta, pf, ws, T, H, t_seg0, nt_seg, l2norm, nullptr);
 }
 
 // ==================================================================================================
@@ -896,9 +943,33 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int L, int NCW, bool F8>
+// Single-launch form (small grids: every workgroup of the pre-pass AND of the scan is resident at once): the scan workgroups
+// start together with the pre-pass workgroups of the same launch, fetch what does not depend on the records (value tiles, the
+// initial state), and their loader waves wait here for the flags of the head's records.  flags[16 bh + c] is raised by the
+// pre-pass workgroup of (chunk c, head bh) and cleared again by the LAST of the head's scan workgroups to have passed the wait
+// (counted in headdone[bh], which it also clears): the area is all-zero between launches -- the caller zeroes it once.
+constexpr int SYNC_HEAD_WORDS = 16;       // flag words per head (chunks of the call: the single-launch form takes <= 16)
+struct ScanSync {
+  unsigned int* flags = nullptr;
+  unsigned int* headdone = nullptr;
+  int BH = 0;
+};
+__device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
+  const unsigned int* p = sy.flags + bh * SYNC_HEAD_WORDS + (lane < nt_seg ? lane : 0);   // lane c watches chunk c: one 64-byte line per head
+  // bounded (~0.1 s): the pre-pass workgroups have lower block ids and are dispatched first, so the wait ends within the
+  // pre-pass's few microseconds; the bound only keeps a broken contract (a sync area shared by concurrent calls) from
+  // hanging the device
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_ballot_w64(v == 0u) == 0ull) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+template <int L, int NCW, bool F8, bool SYNC>
 __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned int lds0, unsigned int lane16, const ScanTouch& tc,
-                                            int lane) {
+                                            int lane, const ScanSync& sy, int bh, bool trace_wg) {
+  (void)trace_wg;
   constexpr int N1 = loader_n1(L, F8), N2 = loader_n2(L, F8);               // pieces per half image issued by this loader
   // NCW = 4: the V waves load their rows / Tu / beta themselves, loaders 2, 3 warm the L2 for them (one touch per chunk)
   // NCW = 2: the loaders fetch the value tile, beta (with H2: the "T batch") and Tu (with H1: the "M batch") for real
@@ -915,18 +986,42 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   };
   // issue order at the start: chunk 0's value tile, beta, Tu (the V waves' conversion + product of chunk 0 stand between their
   // arrival and the first chunk step) | H1(0) | chunk 1's set | H2(0) | H1(1) | touches
-  vset(0);
-  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
-  load_h1<L, F8>(rec(0), img(0), lane16);
-  vset(1);
-  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
-  load_h2<L, F8>(rec(0), img(0), lane16);
-  if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
-  touch_chunk<TW, F8>(tc, ws_bh, 3, nt_seg, lane);
-  touch_chunk<TW, F8>(tc, ws_bh, 4, nt_seg, lane);
-  if (nt_seg > 1) wait_vm<N1 + NVB + NTU + N2 + N1 + 2 * NT>();   // chunk 0's value tile / beta / Tu have landed
-  else wait_vm<N1 + NVB + NTU + N2 + 2 * NT>();
+  if constexpr (SYNC) {
+    // single launch: the value tiles of chunks 0 and 1 do not come from the pre-pass -- requested before the wait
+    static_assert(VD, "the single-launch form is built on the 32-column workgroup");
+    constexpr int NB = L == 3 ? 1 : 0;
+    load_vt<L, F8>(tc, 0, nt_seg, lane);
+    load_vt<L, F8>(tc, 1, nt_seg, lane);
+    scan_wait_records(sy, bh, nt_seg, lane);
+#ifdef IVL_TRACE
+    if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[42] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    load_beta<L, F8>(tc, ws_bh, 0, nt_seg, lane);
+    load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
+    load_h1<L, F8>(rec(0), img(0), lane16);
+    load_beta<L, F8>(tc, ws_bh, 1, nt_seg, lane);
+    load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
+    load_h2<L, F8>(rec(0), img(0), lane16);
+    if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
+    if (nt_seg > 1) wait_vm<N1 + NB + NTU + N2 + N1>();          // chunk 0's beta / Tu have landed (its value tile long before)
+    else wait_vm<N1 + NB + NTU + N2>();
+  } else {
+    vset(0);
+    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
+    load_h1<L, F8>(rec(0), img(0), lane16);
+    vset(1);
+    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
+    load_h2<L, F8>(rec(0), img(0), lane16);
+    if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
+    touch_chunk<TW, F8>(tc, ws_bh, 3, nt_seg, lane);
+    touch_chunk<TW, F8>(tc, ws_bh, 4, nt_seg, lane);
+    if (nt_seg > 1) wait_vm<N1 + NVB + NTU + N2 + N1 + 2 * NT>();   // chunk 0's value tile / beta / Tu have landed
+    else wait_vm<N1 + NVB + NTU + N2 + 2 * NT>();
+  }
   lds_barrier();                                               // PA
+#ifdef IVL_TRACE
+  if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[43] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   lds_barrier();                                               // P0: the V waves are done with tile 0
   vset(2);
   if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT + NVB>();           // H1(0) and chunk 1's set have landed
@@ -959,7 +1054,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     IVL_TACC(lt_iss1, l6, l5);
   }
 #ifdef IVL_TRACE
-  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (ivl_trace_buf != nullptr && lane == 0 && trace_wg) {
     long long* tb = ivl_trace_buf + 64 + 8 * L;
     tb[0] = lt_vmT; tb[1] = lt_wT; tb[2] = lt_iss2; tb[3] = lt_vmM; tb[4] = lt_wM; tb[5] = lt_iss1;
   }
@@ -991,8 +1086,9 @@ constexpr int SCAN_NV = 4;                             // V waves per workgroup:
 
 template <int NCW, bool F8, bool VCONV>
 __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* ws_bh, unsigned char* smem, int vw, int slab_wg,
-                                           int b, int h, int H, int T, int t_seg0, int nt_seg, int lane) {
+                                           int b, int h, int H, int T, int t_seg0, int nt_seg, int lane, bool trace_wg) {
   using R = Rec<F8>;
+  (void)trace_wg;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   // V wave vw owns chunk rows 16 vw .. 16 vw + 15 of the workgroup's 16 NCW columns: a thread = 4 consecutive tokens (run) x
   // NCW channels (NP = NCW / 2 packed bf16 pairs: one 8- or 4-byte load per row), 4 runs x 16 channel groups per wave.
@@ -1259,12 +1355,12 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   }
   lds_barrier();                         // F
 #ifdef IVL_TRACE
-  if (ivl_trace_buf != nullptr && lane == 0 && vw == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (ivl_trace_buf != nullptr && lane == 0 && vw == 0 && trace_wg) {
     ivl_trace_buf[31] = tv_1 - tv_0; ivl_trace_buf[32] = tv_2 - tv_1; ivl_trace_buf[33] = tv_3 - tv_2;
     ivl_trace_buf[34] = tv_wT; ivl_trace_buf[35] = tv_mma; ivl_trace_buf[36] = tv_wM; ivl_trace_buf[37] = tv_conv;
     ivl_trace_buf[38] = tv_x1; ivl_trace_buf[39] = tv_x2; ivl_trace_buf[40] = tv_x3;
   }
-  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (ivl_trace_buf != nullptr && lane == 0 && trace_wg) {
     ivl_trace_buf[104 + 2 * vw] = tv_wT; ivl_trace_buf[105 + 2 * vw] = tv_wM;
   }
 #endif
@@ -1320,13 +1416,17 @@ __device__ __forceinline__ void scan_role(int w, int& role, int& idx) {
   }
 }
 
-template <int NCW, bool F8, bool VCONV>
-__global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_scan_kernel(
-    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv,
+// One scan workgroup: batch*head bx, column slab by.  SYNC (single-launch form): the records are written by pre-pass
+// workgroups of the SAME launch; `sync` -> ScanSync tells the loader waves where to wait for them.
+template <int NCW, bool F8, bool VCONV, bool SYNC>
+__device__ __forceinline__ void gdn_chunk_scan_body(
+    unsigned char* smem, const int bx, const int by,
+    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o, const ScanV& sv,
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
-    int T, int H, int t_seg0, int nt_seg, float scale) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    int T, int H, int t_seg0, int nt_seg, float scale, const ScanSync sy) {
   using R = Rec<F8>;
+  const bool trace_wg = bx == 0 && by == 0;
+  (void)trace_wg;
   using frag_t = typename FragT<F8>::type;
   constexpr int IMG_BYTES = Img<F8>::BYTES, BLK = R::BLK;
 
@@ -1340,7 +1440,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   const int j = lane & 15, g = lane >> 4;
   // grid = (B*H, 16/NCW): linear block id = bh + B*H*slab, so with B*H % 8 == 0 all column slabs of one head run on
   // the same XCD (id % 8) and share its L2 for the record they all read.
-  const int bh = blockIdx.x;
+  const int bh = bx;
   const int b = bh / H, h = bh % H;
   const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)smem);
   const unsigned int lane16 = lane * 16;                          // DMA piece offset
@@ -1352,25 +1452,25 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   if (role == ROLE_LOAD) {                                      // ---- loader waves ----
     static_assert(SCAN_NL == 4, "loader dispatch below");
     ScanTouch tc;
-    tc.vrow0 = (const unsigned char*)(sv.v + (size_t)b * T * sv.ld + sv.col0 + h * GV + (int)blockIdx.y * (16 * NCW));
+    tc.vrow0 = (const unsigned char*)(sv.v + (size_t)b * T * sv.ld + sv.col0 + h * GV + by * (16 * NCW));
     tc.row_bytes = (unsigned int)sv.ld * 2u;
     tc.T = T; tc.t_seg0 = t_seg0;
     tc.dummy = lds0 + (unsigned int)Img<F8>::dummy(NCW);
     tc.vt = lds0 + (unsigned int)Img<F8>::vt(NCW);
     tc.tub = lds0 + (unsigned int)Img<F8>::tub(NCW);
     tc.betab = lds0 + (unsigned int)Img<F8>::betab(NCW);
-    if (ridx == 0) scan_loader<0, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
-    else if (ridx == 1) scan_loader<1, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
-    else if (ridx == 2) scan_loader<2, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
-    else scan_loader<3, NCW, F8>(ws_bh, nt_seg, lds0, lane16, tc, lane);
+    if (ridx == 0) scan_loader<0, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else if (ridx == 1) scan_loader<1, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else if (ridx == 2) scan_loader<2, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else scan_loader<3, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
     return;
   }
   if (role == ROLE_V) {                                         // ---- V waves ----
-    scan_vwave<NCW, F8, VCONV>(sv, ws_bh, smem, ridx, (int)blockIdx.y, b, h, H, T, t_seg0, nt_seg, lane);
+    scan_vwave<NCW, F8, VCONV>(sv, ws_bh, smem, ridx, by, b, h, H, T, t_seg0, nt_seg, lane, trace_wg);
     return;
   }
   const int pair = ridx;
-  const int v0 = (blockIdx.y * NCW + pair) * 16;                // first state column of this pair
+  const int v0 = (by * NCW + pair) * 16;                // first state column of this pair
   unsigned char* xsb = smem + Img<F8>::xch(NCW) + pair * Img<F8>::XCH_PAIR;   // sb: 4 fragment blocks, lane-linear
   unsigned char* xvn = xsb + 4 * BLK;                                         // v_new: 2 fragment blocks
   auto frag = [&](const unsigned char* im, int off, int idx) { return *(const frag_t*)(im + off + idx * BLK + lanef); };
@@ -1380,6 +1480,16 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     frag_t fq[16];
     float egv[4];
     lds_barrier();                       // PA
+    if constexpr (SYNC) {
+      // behind PA every loader wave of this workgroup has seen the head's flags: the last of the head's scan workgroups to
+      // get here clears them (and the count) for the next launch
+      if (pair == 0 && lane == 0) {
+        if (atomicAdd(sy.headdone + bh, 1u) == (unsigned int)(16 / NCW - 1)) {
+          for (int c = 0; c < nt_seg; ++c) __hip_atomic_store(sy.flags + bh * SYNC_HEAD_WORDS + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sy.headdone + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     lds_barrier();                       // P0
     lds_barrier();                       // P: H1(0) has landed
 #pragma unroll
@@ -1444,10 +1554,10 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
       IVL_TACC(ot_wT, o1, o0); IVL_TACC(ot_A, o2, o1); IVL_TACC(ot_wM, o3, o2); IVL_TACC(ot_B, o4, o3);
     }
 #ifdef IVL_TRACE
-    if (ivl_trace_buf != nullptr && lane == 0 && pair == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (ivl_trace_buf != nullptr && lane == 0 && pair == 0 && trace_wg) {
       ivl_trace_buf[100] = ot_wT; ivl_trace_buf[101] = ot_A; ivl_trace_buf[102] = ot_wM; ivl_trace_buf[103] = ot_B;
     }
-    if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (ivl_trace_buf != nullptr && lane == 0 && trace_wg) {
       ivl_trace_buf[112 + 2 * pair] = ot_wT; ivl_trace_buf[113 + 2 * pair] = ot_wM;
     }
 #endif
@@ -1464,7 +1574,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   static_assert(GK * TROW <= NCW * Img<F8>::XCH_PAIR || F8, "state tile must fit the exchange area");
   constexpr bool TILE_OK = GK * TROW <= NCW * Img<F8>::XCH_PAIR;
   const int stid = pair * 64 + lane;                               // thread index among the state waves
-  const size_t srow0 = (size_t)bh * GK * GV + (size_t)blockIdx.y * (16 * NCW);   // element offset of the workgroup's columns in row 0
+  const size_t srow0 = (size_t)bh * GK * GV + (size_t)by * (16 * NCW);   // element offset of the workgroup's columns in row 0
   f32x4 S[8];
   bool tiled_in = false;
   {
@@ -1601,20 +1711,65 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
   }
   lds_barrier();                         // F (matches the other roles' count)
   IVL_T(ts2);
-  IVL_TOUT(16, ts0); IVL_TOUT(17, t_bar); IVL_TOUT(18, t_h1); IVL_TOUT(19, t_h2); IVL_TOUT(20, ts1 - ts0); IVL_TOUT(21, ts2 - ts1);
+  IVL_TOUT_WG(trace_wg, 16, ts0); IVL_TOUT_WG(trace_wg, 17, t_bar); IVL_TOUT_WG(trace_wg, 18, t_h1); IVL_TOUT_WG(trace_wg, 19, t_h2); IVL_TOUT_WG(trace_wg, 20, ts1 - ts0); IVL_TOUT_WG(trace_wg, 21, ts2 - ts1);
 #ifdef IVL_TRACE
-  IVL_TOUT(25, (long long)__builtin_amdgcn_s_memrealtime() - rt0);
+  IVL_TOUT_WG(trace_wg, 25, (long long)__builtin_amdgcn_s_memrealtime() - rt0);
+  IVL_TOUT_WG(trace_wg, 41, rt0);
+  IVL_TOUT_WG(trace_wg, 44, (long long)__builtin_amdgcn_s_memrealtime());
 #endif
-  IVL_TOUT(22, ts2); IVL_TOUT(23, t_bar2); IVL_TOUT(24, t_sb);
+  IVL_TOUT_WG(trace_wg, 22, ts2); IVL_TOUT_WG(trace_wg, 23, t_bar2); IVL_TOUT_WG(trace_wg, 24, t_sb);
 #ifdef IVL_TRACE
-  if (ivl_trace_buf != nullptr && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (ivl_trace_buf != nullptr && lane == 0 && trace_wg) {
     ivl_trace_buf[120 + 2 * pair] = t_bar; ivl_trace_buf[121 + 2 * pair] = t_bar2;
   }
 #endif
 }
 
+
+template <int NCW, bool F8, bool VCONV>
+__global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_scan_kernel(
+    const unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv,
+    const void* h0, int h0_dtype, void* ht, int ht_dtype,
+    int T, int H, int t_seg0, int nt_seg, float scale) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  gdn_chunk_scan_body<NCW, F8, VCONV, false>(smem, (int)blockIdx.x, (int)blockIdx.y, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0,
+                                             nt_seg, scale, ScanSync{});
+}
+
+// Single launch of the fused call at small grids (the benchmark's streaming step: 64 pre-pass + 128 scan workgroups on 256
+// CUs).  Blocks [0, nt_seg BH) are pre-pass workgroups (waves 8-11 leave at once), the rest scan workgroups; both kinds need
+// no more than one CU each, and every block is resident from the start: the scan side can wait for the pre-pass side
+// (scan_wait_records) without a second launch -- one launch boundary (~4.5 us inside the step's graph) and the scan's own
+// start-up (state tile, value tiles, conv of chunks 0 and 1) disappear behind the pre-pass.
+// With BH % 8 == 0 the pre-pass workgroup of head bh gets a block id = bh (mod 8): the same die (id % 8) as the head's scan
+// workgroups, whose L2 then holds the record it is about to be asked for.
+constexpr int SINGLE_THREADS = 64 * (2 * 2 + SCAN_NL + SCAN_NV);
+constexpr int SINGLE_MAX_BLOCKS = 256;
+constexpr int G_SYNC_BYTES = IVL_GDN_SYNC_BYTES;   // flags: 16 words per head (<= 32 heads) at 0; headdone: words at 2048
+static_assert(G_SYNC_BYTES >= 2048 + 4 * 32, "sync area layout");
+template <bool F8>
+__global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
+    PrepFused pf, unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv, const void* h0, int h0_dtype, void* ht,
+    int ht_dtype, int T, int H, int BH, int nt_seg, float scale, ScanSync sy) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int nprep = nt_seg * BH;
+  int id = (int)blockIdx.x;
+  if (id < nprep) {
+    if (threadIdx.x >= 512) return;
+    int bh, ci;
+    if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
+    else { bh = id / nt_seg; ci = id % nt_seg; }
+    gdn_chunk_prepare_body<F8, true, true>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1,
+                                     sy.flags + bh * SYNC_HEAD_WORDS + ci);
+  } else {
+    id -= nprep;
+    gdn_chunk_scan_body<2, F8, true, true>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, 0, nt_seg, scale, sy);
+  }
+}
+
 #ifdef IVL_TRACE
 int g_scan_ncw = 0;                        // developer knob (trace build only): force 2 or 4 compute waves per scan workgroup
+int g_gdn_single = 1;                      // developer knob (trace build only): 0 = never take the single-launch form
 #endif
 
 }  // namespace ivl
@@ -1641,6 +1796,8 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
     scan_set_attr<4, false, false>(); scan_set_attr<2, false, false>(); scan_set_attr<4, true, false>(); scan_set_attr<2, true, false>();
     scan_set_attr<4, false, true>(); scan_set_attr<2, false, true>(); scan_set_attr<4, true, true>(); scan_set_attr<2, true, true>();
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true>, attr, scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES);
   });
 }
 
@@ -1662,7 +1819,7 @@ static void scan_launch(int B, int H, hipStream_t st, const unsigned char* wsb, 
 template <bool F8>
 static int gdn_chunk_launch(const void* q, const void* k, const void* v, const float* g, const void* beta, const PrepFused* pf, void* o,
                             const void* h0, int h0_dtype, void* ht, int ht_dtype, int B, int T, int H, float scale,
-                            int use_qk_l2norm, unsigned char* wsb, hipStream_t st) {
+                            int use_qk_l2norm, unsigned char* wsb, unsigned int* sync, hipStream_t st) {
   const int NT = (T + GC - 1) / GC;
   const int segc = seg_chunks(NT);
   float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * Rec<false>::STRIDE) : nullptr;
@@ -1676,6 +1833,18 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
     sv.v = pf->proj; sv.ld = pf->ld; sv.col0 = pf->col_v; sv.w = pf->w[2]; sv.st_in = pf->st_in[2]; sv.st_out = pf->st_out[2];
   } else {
     sv.v = (const bf16_t*)v; sv.ld = (long long)H * GV; sv.col0 = 0; sv.w = nullptr; sv.st_in = nullptr; sv.st_out = nullptr;
+  }
+  bool single = pf != nullptr && sync != nullptr && ncw == 2 && NT <= SYNC_HEAD_WORDS && NT * B * H + (16 / 2) * B * H <= SINGLE_MAX_BLOCKS;
+#ifdef IVL_TRACE
+  single = single && g_gdn_single != 0;
+#endif
+  if (single) {
+    ScanSync sy;
+    sy.flags = sync; sy.headdone = sync + 512; sy.BH = B * H;
+    const int lds = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
+    hipLaunchKernelGGL((gdn_chunk_single_kernel<F8>), dim3(NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb, (bf16_t*)o, sv,
+                       h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
+    return check_launch("ivl_gdn_chunk_fused_fwd(single launch)");
   }
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
@@ -1724,9 +1893,9 @@ extern "C" int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, co
   gdn_chunk_init_device();
   if (mma_dtype == IVL_FP8_E4M3)
     return gdn_chunk_launch<true>(q, k, v, g, beta, nullptr, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
-                                  (unsigned char*)workspace, (hipStream_t)stream);
+                                  (unsigned char*)workspace, nullptr, (hipStream_t)stream);
   return gdn_chunk_launch<false>(q, k, v, g, beta, nullptr, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, use_qk_l2norm,
-                                 (unsigned char*)workspace, (hipStream_t)stream);
+                                 (unsigned char*)workspace, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
@@ -1734,7 +1903,7 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
                                        const void* sv_in, void* sq_out, void* sk_out, void* sv_out, const float* A_log,
                                        const float* dt_bias, void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype, int B,
                                        int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       size_t workspace_bytes, void* sync, void* stream) {
   IVL_REQUIRE(proj && wq && wk && wv && A_log && dt_bias && o, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: NULL pointer");
   IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
   IVL_REQUIRE(K == GK && V == GV && conv_width == 4, IVL_ERR_UNSUPPORTED,
@@ -1754,6 +1923,7 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
   const size_t need = ivl_gdn_chunk_workspace_bytes(B, T, H, K, V);
   IVL_REQUIRE(workspace != nullptr && workspace_bytes >= need, IVL_ERR_WORKSPACE,
               "ivl_gdn_chunk_fused_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+  IVL_REQUIRE(sync == nullptr || ((size_t)sync & 15) == 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: sync area must be 16-byte aligned");
   gdn_chunk_init_device();
   PrepFused pf;
   pf.proj = (const bf16_t*)proj; pf.ld = ld;
@@ -1764,7 +1934,7 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
   pf.A_log = A_log; pf.dt_bias = dt_bias;
   if (mma_dtype == IVL_FP8_E4M3)
     return gdn_chunk_launch<true>(nullptr, nullptr, nullptr, nullptr, nullptr, &pf, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, 1,
-                                  (unsigned char*)workspace, (hipStream_t)stream);
+                                  (unsigned char*)workspace, (unsigned int*)sync, (hipStream_t)stream);
   return gdn_chunk_launch<false>(nullptr, nullptr, nullptr, nullptr, nullptr, &pf, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, 1,
-                                 (unsigned char*)workspace, (hipStream_t)stream);
+                                 (unsigned char*)workspace, (unsigned int*)sync, (hipStream_t)stream);
 }

@@ -536,6 +536,9 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
   const int b = bz / p.nsplit, split = bz % p.nsplit;
   const int hk = hq / G;
   IVL_T(tr_start);
+#ifdef IVL_TRACE
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
@@ -717,11 +720,17 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
     };
     static_assert(PF_H1 == 5, "wait_older counts PF_H1 instructions");
     IVL_TVAR(tl_k); IVL_TVAR(tl_kw); IVL_TVAR(tl_v); IVL_TVAR(tl_vw);
+    IVL_T(tl_s0);
     fetch(0, 0); fetch(0, 1);
     fetch(1, 0); fetch(1, 1);
     bool newest = false;
+    IVL_T(tl_s1);
     wait_older(false);
+    IVL_T(tl_s2);
     seg_barrier();                              // tiles 0 and 1 are in LDS: the compute waves start
+    IVL_T(tl_s3);
+    IVL_TOUT_AT(512, 41, tl_s0 - tr_start); IVL_TOUT_AT(512, 43, tl_s1 - tl_s0); IVL_TOUT_AT(512, 46, tl_s2 - tl_s1); IVL_TOUT_AT(512, 48, tl_s3 - tl_s2);
+    IVL_TOUT_AT(640, 49, tl_s1 - tl_s0); IVL_TOUT_AT(640, 54, tl_s2 - tl_s1);
     // K(i): stage free from segment 2i - 4, complete before barrier 2i - 1: issued in segments 2i - 4 | 2i - 3, waited for in 2i - 1.
     // V(i): free from 2i - 3, complete before barrier 2i: issued in segments 2i - 3 | 2i - 2, waited for in 2i.
 #pragma nounroll
@@ -1000,6 +1009,10 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       const long long v = ((tr_fin - tr_start) << 24) | ((long long)(kt_end - kt_begin) << 16) | ((long long)split << 8) | bx;
       atomicMax((unsigned long long*)ivl_trace_buf + 44, (unsigned long long)v);
       atomicMin((unsigned long long*)ivl_trace_buf + 45, (unsigned long long)v);
+      // spread of the launch on the shared 100 MHz clock: first workgroup start (29), last start (31), last end (30)
+      atomicMin((unsigned long long*)ivl_trace_buf + 29, rt_start);
+      atomicMax((unsigned long long*)ivl_trace_buf + 31, rt_start);
+      atomicMax((unsigned long long*)ivl_trace_buf + 30, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 #endif
     IVL_TOUT(33, tr_a); IVL_TOUT(34, tr_wa); IVL_TOUT(35, tr_b); IVL_TOUT(36, tr_wb);

@@ -191,6 +191,23 @@ def chunk_gated_delta_rule(
     return (o.transpose(1, 2) if head_first else o), ht
 
 
+_GDN_SYNC: Dict[int, torch.Tensor] = {}
+_GDN_SINGLE_LAUNCH = True      # tests switch it off to compare the single-launch form with the two-launch form
+
+
+def _gdn_sync_area(device: torch.device) -> torch.Tensor:
+    """The flag words of ivl_gdn_chunk_fused_fwd's single-launch form (include/ivl_hip.h): zeroed here once, then owned by
+    the library (every launch leaves it all-zero).  One per device: the package issues its calls on one stream."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    area = _GDN_SYNC.get(dev)
+    if area is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the GDN sync area would have to be created during hipGraph capture; run a warm-up step first")
+        area = torch.zeros(_lib.IVL_GDN_SYNC_BYTES, dtype=torch.uint8, device=device)
+        _GDN_SYNC[dev] = area
+    return area
+
+
 def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv_states_out, A_log32, dt_bias32,
                     H: int, K: int, V: int, scale=None, initial_state=None, final_state_out=None, mma_dtype=None):
     """Chunked gated delta rule with its front end (3 short convs + SiLU + gate math) inside the pre-pass: one call from
@@ -217,7 +234,7 @@ def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv
         _p(si[0]), _p(si[1]), _p(si[2]), _p(so[0]), _p(so[1]), _p(so[2]), _p(A_log32), _p(dt_bias32), _p(o),
         _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32, _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
         B, T, H, K, V, wq.shape[-1], float(K ** -0.5 if scale is None else scale), mma_code(mma_dtype), _p(ws), ws.numel(),
-        _stream(proj)))
+        _p(_gdn_sync_area(proj.device)) if _GDN_SINGLE_LAUNCH else None, _stream(proj)))
     return o
 
 

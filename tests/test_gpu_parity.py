@@ -1554,6 +1554,78 @@ def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("B,T,hist", [(1, 256, True), (1, 512, True), (1, 64, False), (1, 300, True), (1, 7, True)])
+def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
+    """ivl_gdn_chunk_fused_fwd with a sync area (pre-pass and scan workgroups of ONE launch, the scan side waiting on flags) must
+    equal the two-launch form bit for bit -- outputs, final state, conv states -- call after call (the launch clears its own
+    flags: the area is all-zero afterwards) and when replayed from a hipGraph."""
+    from infinitevl_amd import ops
+    H, K, V = 16, 128, 256
+    Dq, Dk, Dv = H * K, H * K, H * V
+    g_ = torch.Generator(device=DEV).manual_seed(B * 77 + T)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+    ld = cols[4] + H
+    cw = [rn(D_, 1, 4) * 0.5 for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.randn(H, device=DEV, generator=g_), torch.randn(H, device=DEV, generator=g_)
+
+    def run(proj, cs, h0, single):
+        so = [c.clone() for c in cs] if hist else [torch.zeros(B, D_, 4, dtype=torch.bfloat16, device=DEV) for D_ in (Dq, Dk, Dv)]
+        ht = torch.zeros(B, H, K, V, dtype=torch.bfloat16, device=DEV)
+        ops._GDN_SINGLE_LAUNCH = single
+        try:
+            o = ops.gdn_chunk_fused(proj, cols, cw, so if hist else [None] * 3, so, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht)
+        finally:
+            ops._GDN_SINGLE_LAUNCH = True
+        return o, ht, so
+
+    area = ops._gdn_sync_area(DEV)
+    # the two-launch reference of every input set first, then the single-launch calls back to back: a record line left in
+    # some L2 by an earlier launch would belong to different inputs
+    sets, refs = [], []
+    for it in range(10):
+        st = (rn(B, T, ld), [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)],
+              bf(torch.randn(B, H, K, V, device=DEV, generator=g_) * 0.1) if hist else None)
+        sets.append(st)
+        refs.append(run(*st, False))
+    for rep in range(2):
+        outs = [run(*st, True) for st in sets]
+        for it, ((o2, ht2, so2), (o1, ht1, so1)) in enumerate(zip(refs, outs)):
+            assert torch.equal(o1, o2) and torch.equal(ht1, ht2), (rep, it)
+            for a, b_ in zip(so1, so2):
+                assert torch.equal(a, b_)
+        assert int(area.view(torch.int32).abs().sum()) == 0, "the launch must leave its flags cleared"
+    # hipGraph replay of the single-launch form: static inputs rewritten between replays
+    proj = rn(B, T, ld)
+    so = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    st = bf(torch.randn(B, H, K, V, device=DEV, generator=g_) * 0.1)
+    o_static = torch.empty(B, T, H, V, dtype=torch.bfloat16, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gdn_chunk_fused(proj, cols, cw, [c.clone() for c in so], [c.clone() for c in so], A32, dt32, H, K, V, initial_state=st.clone(),
+                            final_state_out=st.clone())
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_static.copy_(ops.gdn_chunk_fused(proj, cols, cw, so, so, A32, dt32, H, K, V, initial_state=st, final_state_out=st))
+    for it in range(6):
+        proj.copy_(rn(B, T, ld))
+        so_ref = [c.clone() for c in so]
+        st_ref = st.clone()
+        ops._GDN_SINGLE_LAUNCH = False
+        try:
+            o_ref = ops.gdn_chunk_fused(proj, cols, cw, so_ref, so_ref, A32, dt32, H, K, V, initial_state=st_ref, final_state_out=st_ref)
+        finally:
+            ops._GDN_SINGLE_LAUNCH = True
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o_static, o_ref) and torch.equal(st, st_ref), it
+        for a, b_ in zip(so, so_ref):
+            assert torch.equal(a, b_)
+    assert int(area.view(torch.int32).abs().sum()) == 0
+
+
 def test_rope_tables_kernel_matches_the_eager_chain():
     """ivl_rope_tables_fwd == the reference's eager rotary chain (std:896-930) on the same positions: identical bf16 tables
     (cos / sin in fp32 from the same fp32 product, rounded once), 3-D positions with distinct axes, large positions."""

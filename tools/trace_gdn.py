@@ -21,6 +21,8 @@ trace = torch.zeros(128, dtype=torch.int64, device=dev)
 lib.ivl_debug_set_trace.argtypes = [ctypes.c_void_p]
 run = lambda: ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=state, use_qk_l2norm_in_kernel=True,
                                          final_state_out=state)
+if os.environ.get("IVL_TRACE_TWO"):            # the two-launch form of the fused call
+    ops._GDN_SINGLE_LAUNCH = False
 if os.environ.get("IVL_TRACE_FUSED"):          # the pre-pass with the conv / gate front end (developer tool only)
     Dq, Dk, Dv = H * K, H * K, H * V
     cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
@@ -45,6 +47,9 @@ for it in range(3):
     print(f"    fused front end (wave 0): loads issued {t[8]} | state hand-over {t[9]} | conv q {t[10]} | conv k {t[11]}")
     print(f"    v wave 7: loads issued {t[12]} | state hand-over {t[13]} | conv v {t[14]} | arrival at B1: wave 0 {t[15]}, wave 1 {t[30]}, wave 7 {t[29]}")
     print(f"    prepare launch on the 100 MHz clock: first workgroup start -> last end {(t[27]-t[26]) * 10} ns, longest workgroup {t[28] * 10} ns")
+    if t[42]:
+        print(f"    single launch, ns after the first pre-pass workgroup's start: scan workgroup 0 starts {(t[41]-t[26]) * 10} | last pre-pass end {(t[27]-t[26]) * 10} "
+              f"| flags seen {(t[42]-t[26]) * 10} | PA {(t[43]-t[26]) * 10} | scan end {(t[44]-t[26]) * 10}")
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
           f"| scan realtime ticks {t[25]} -> {(t[22]-t[16]) / max(t[25], 1) * 100:.0f} MHz if the tick is 100 MHz")
