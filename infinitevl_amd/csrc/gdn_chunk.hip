@@ -238,13 +238,22 @@ __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x
 }
 
 // The pre-pass of one (chunk ci, batch*head bh) by the first 512 threads of the workgroup.  `done` (single-launch form only):
-// the word the scan workgroups of this head poll -- set once the whole record is visible device-wide.
-template <bool F8, bool FUSED, bool DEV>
+// the word the scan workgroups of this head poll -- raised once the workgroup's part of the record is visible device-wide.
+// ROLE (single-launch form, when the chip has room for twice the pre-pass workgroups): 0 = the whole pre-pass;
+//   1 = the k side: conv + l2norm of k ONLY (all eight waves, runs of two tokens), gates, L, T = (I + L)^-1, w, Tu, Kd -- the
+//       chain the scan waits for, without the q half of the front end and without Aqk / q_hat;
+//   2 = the q side: conv + l2norm of q and k (as ROLE 0), q_hat, Aqk.
+// With ROLE != 0 the gate step P1a runs on a ninth wave (wave 8, which leaves behind B1) instead of behind wave 1's conv work.
+// The conv state of k is read by BOTH workgroups of chunk 0 and written (possibly in place) by the k side: the q side raises
+// `kread` once its loads of the old state have returned, the k side writes the new state at its very end, behind that word.
+template <bool F8, bool FUSED, bool DEV, int ROLE>
 __device__ __forceinline__ void gdn_chunk_prepare_body(
     unsigned char* smem, const int ci, const int bh,
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, const PrepFused& pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm,
-    unsigned int* done) {
+    unsigned int* done, unsigned int* kread) {
+  static_assert(ROLE == 0 || FUSED, "the split pre-pass exists for the fused front end only");
+  constexpr bool KONLY = ROLE == 1, DO_K = ROLE != 2, DO_Q = ROLE != 1;
   using R = Rec<F8>;
   bf16_t* s_kh = (bf16_t*)(smem + P_KH);
   bf16_t* s_qh = (bf16_t*)(smem + P_QH);
@@ -274,15 +283,17 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   //         that the three tokens in front of a run are loaded once; conv + SiLU of the run; the value side is not touched
   //         here at all (round 3: it belongs to the scan's V waves)
   const int oct = tid & 15;
-  const bool is_k = wave_u >= 4;                     // fused: the array this wave converts (wave-uniform)
+  const bool is_k = KONLY || wave_u >= 4;            // fused: the array this wave converts (wave-uniform)
+  const bool front = ROLE == 0 || wave_u < 8;        // (ROLE != 0: wave 8 only runs P1a)
   // SIMD s hosts waves s and s + 4.  Three pieces of single-wave work sit in front of B1: the conv-state hand-over of q (the
   // threads that hold rows 0-3: wave 0), of k (wave 6: the k runs are rotated by 8) and the gate / cumsum step P1a (wave 1):
   // three different SIMDs.
-  const int r0 = FUSED ? (is_k ? ((tid >> 4) + 8) & 15 : (tid >> 4) & 15) : tid >> 4;
-  constexpr int NQK = FUSED ? 4 : 2;                 // rows per thread (fused: of ONE array)
+  const int r0 = FUSED ? (KONLY ? (tid >> 4) & 31 : (is_k ? ((tid >> 4) + 8) & 15 : (tid >> 4) & 15)) : tid >> 4;
+  constexpr int NQK = FUSED ? (KONLY ? 2 : 4) : 2;   // rows per thread (fused: of ONE array)
   u32x4 kraw[NQK], qraw[NQK];                        // fused: only the wave's own array is populated
   bf16_t braw[NQK];
-  constexpr int P1A_WAVE = 1;
+  constexpr int P1A_WAVE = ROLE == 0 ? 1 : 8;
+  u32x4 keep_tl[4], keep_h[3];                       // ROLE 1: the k conv-state hand-over is written at the end (see above)
   // the P1a wave also fetches the chunk's gate inputs here (consumed in P1a, behind its conv work: requested there they were
   // a memory round trip of their own on the wave every other one waits for at B1)
   float p1_g = 0.f, p1_b = 0.f, p1_dt = 0.f, p1_A = 0.f;
@@ -299,7 +310,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       p1_b = bf2f(beta[tok1]);
     }
   }
-  auto qk_row = [&](int rr) { return FUSED ? 4 * r0 + rr : r0 + 32 * rr; };
+  auto qk_row = [&](int rr) { return FUSED ? NQK * r0 + rr : r0 + 32 * rr; };
   if constexpr (!FUSED) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -387,42 +398,60 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       }
     };
     const bool own_state = t0 == 0;                                    // this workgroup holds time 0
-    {
+    if (front) {
       const int a = is_k ? 1 : 0;                                      // 0: q, 1: k (wave-uniform)
-      u32x4 xr[7], wt[4];
+      u32x4 xr[NQK + 3], wt[4];
       const int col = (is_k ? pf.col_k : pf.col_q) + h * GK + 8 * oct;
-      load_run(xr, 4 * r0, std::integral_constant<int, 4>{}, col);
+      load_run(xr, NQK * r0, std::integral_constant<int, NQK>{}, col);
       const u32x4* wp = (const u32x4*)(pf.w[a] + ((size_t)h * GK + 8 * oct) * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) wt[i] = wp[i];
-      bf16_t bin[4] = {0, 0, 0, 0};
+      bf16_t bin[NQK] = {};
       if (is_k) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int tg = min(t0 + 4 * r0 + rr, T - 1);
+        for (int rr = 0; rr < NQK; ++rr) {
+          const int tg = min(t0 + NQK * r0 + rr, T - 1);
           bin[rr] = xb[(unsigned int)tg * ld32 + (unsigned int)(pf.col_b + h)];
         }
       }
       // every load of the thread is in flight before the first one is consumed (in-order return: waiting for any of them
       // waits for all issued before it)
       u32x4 tl[4], st4[4];
+      // (k side: runs of two tokens -- the run that starts at time 2 has time -1, the state's last tap, in front of it too)
+      const bool second_run = KONLY && own_state && r0 == 1;
       if (own_state && r0 == 0) {
         tail_load(tl, col);
+        history_load(st4, pf.st_in[a]);
+      } else if (second_run) {
         history_load(st4, pf.st_in[a]);
       }
       if (is_k) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));     // beta = bf16(sigmoid(b)) (std:1293)
+        for (int rr = 0; rr < NQK; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));     // beta = bf16(sigmoid(b)) (std:1293)
       }
       IVL_T(tf0);
       IVL_TOUT(8, tf0 - tp0);
       if (own_state && r0 == 0) {
         history(xr, st4);
-        put_state(tl, xr, pf.st_out[a]);
+        if (ROLE == 0 || (ROLE == 2 && !is_k)) {
+          put_state(tl, xr, pf.st_out[a]);
+        } else if (ROLE == 1) {                                        // written at the end, behind the q side's `kread`
+#pragma unroll
+          for (int j = 0; j < 4; ++j) keep_tl[j] = tl[j];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) keep_h[j] = xr[j];
+        } else if (pf.st_out[1] != nullptr && oct == 0) {              // ROLE 2, k waves: the old state has been read (history
+          __hip_atomic_store(kread, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed it: the loads have returned)
+        }
+      }
+      if (second_run) {
+        u32x4 hx[3];
+        history(hx, st4);
+        xr[0] = hx[2];                                                 // time -1
       }
       IVL_T(tf1);
-      if (is_k) conv4_silu<4>(xr, wt, kraw);
-      else conv4_silu<4>(xr, wt, qraw);
+      if (is_k) conv4_silu<NQK>(xr, wt, kraw);
+      else conv4_silu<NQK>(xr, wt, qraw);
       IVL_T(tf2);
       IVL_TOUT(9, tf1 - tf0); IVL_TOUT(10, tf2 - tf1);
     }
@@ -452,9 +481,11 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
     s_eg[lane] = e;
     s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
     s_beta[lane] = bv;                               // 0 for padded rows
-    rec_st<DEV>((float*)(rec + R::EG) + lane, e);
-    rec_st<DEV>((bf16_t*)(rec + R::BETA) + lane, f2bf(bv));     // the scan's V waves scale v with it (beta is a bf16 value: exact)
-    if (lane == 0) rec_st<DEV>(rec + R::EGL, __expf(gl));
+    if constexpr (DO_K) {
+      rec_st<DEV>((float*)(rec + R::EG) + lane, e);
+      rec_st<DEV>((bf16_t*)(rec + R::BETA) + lane, f2bf(bv));     // the scan's V waves scale v with it (beta is a bf16 value: exact)
+      if (lane == 0) rec_st<DEV>(rec + R::EGL, __expf(gl));
+    }
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
   auto norm_row = [&](u32x4 xv, int row, bool ok, float* f) {        // f[0..7] = x / |x| (fp32), 0 for a padded row
@@ -482,6 +513,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   };
 #pragma unroll
   for (int rr = 0; rr < NQK; ++rr) {
+    if (!front) break;
     const int row = qk_row(rr);
     const bool ok = row < nvalid;
     float f[8];
@@ -498,6 +530,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   IVL_TOUT(15, tb1 - tp0); IVL_TOUT_AT(448, 29, tb1 - tp0); IVL_TOUT_AT(64, 30, tb1 - tp0);
   __syncthreads();                                   // B1
   IVL_T(tp1);
+  if (ROLE != 0 && wave_u == 8) return;              // the P1a wave is done (later barriers count the live waves only)
 
   // Copy-out of the two operands that are plain re-orderings of the LDS tiles, piece `idx` of 2048:
   //   [0,1024)    QH : piece (block 4m+s, g, i) = q_hat[16m+i][32s + {4g..4g+3, 16+4g..+3}]
@@ -525,7 +558,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   };
 
   // ---- P2: waves 0-2: L = tril(kb kh^T, -1) -> s_L;  waves 3-5: A^T = kh qh^T -> Aqk blocks;  waves 6-7: first copy-outs -----
-  if (wave_u < 3) {
+  if (DO_K && wave_u < 3) {
     const int mi = wave_u == 0 ? 0 : 1, ni = wave_u == 2 ? 1 : 0;       // tiles (0,0), (1,0), (1,1)
     f32x16 acc;
 #pragma unroll
@@ -541,7 +574,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       const int i = 32 * mi + crow32(r, hi);
       s_L[i * P_LDF + j] = i > j ? acc[r] : 0.f;
     }
-  } else if (wave_u < 6) {
+  } else if (DO_Q && wave_u >= 3 && wave_u < 6) {
     const int nj = wave_u == 5 ? 1 : 0, mi = wave_u == 3 ? 0 : 1;       // (key tile, query tile) = (0,0), (0,1), (1,1)
     f32x16 acc;
 #pragma unroll
@@ -568,10 +601,26 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
     for (int p = 0; p < 2; ++p)
       put_piece<F8, DEV>(rec + R::AQK, pc0 + 32 * p, val[4 * p], val[4 * p + 1], val[4 * p + 2], val[4 * p + 3], val[8 + 4 * p], val[9 + 4 * p],
                     val[10 + 4 * p], val[11 + 4 * p]);
-  } else {
+  } else if (ROLE == 0) {
     const int t2 = tid - 384;                        // 0..127
 #pragma unroll
     for (int z = 0; z < 4; ++z) copy_piece(t2 + 128 * z);                 // QH pieces 0..511
+  } else {
+    // split pre-pass: the five waves without a product copy the side's re-ordered operand out (1024 pieces over 320 threads)
+    const int t2 = ROLE == 1 ? tid - 192 : (tid < 192 ? tid : tid - 192);   // k side: waves 3-7; q side: waves 0-2, 6-7
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+      const int idx = t2 + 320 * z;
+      if (idx < 1024) copy_piece((ROLE == 1 ? 1024 : 0) + idx);
+    }
+  }
+  if constexpr (ROLE == 2) {                          // the q side is complete: q_hat and Aqk are on their way
+    if (done != nullptr) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) atomicAdd(done, 1u);
+    }
+    return;
   }
   __syncthreads();                                   // B2: s_L complete
   IVL_T(tp2);
@@ -600,7 +649,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
 #pragma unroll
       for (int i = 0; i < 16; ++i) s_L[(bb + i) * P_LDF + bb + l15] = x[i];
     }
-  } else {
+  } else if (ROLE == 0) {
     const int t2 = tid - 256;                        // 0..255
 #pragma unroll
     for (int z = 0; z < 6; ++z) copy_piece(512 + t2 + 256 * z);           // QH 512..1023, KDT 1024..2047
@@ -725,11 +774,39 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
 #endif
   IVL_TOUT(0, tp0); IVL_TOUT(1, tp1 - tp0); IVL_TOUT(2, tp2 - tp1); IVL_TOUT(3, tp3a - tp2); IVL_TOUT(4, tp3b - tp3a);
   IVL_TOUT(5, tp3 - tp3b); IVL_TOUT(6, tp4 - tp3); IVL_TOUT(7, tp4);
-  if constexpr (DEV) {
+  if constexpr (ROLE == 1) {
+    // the new conv state of k (chunk 0, the sixteen threads that read the old one): the q side's workgroup has read the old
+    // state too once `kread` is up (bounded wait, as scan_wait_records) -- cleared again for the next launch
+    if (t0 == 0 && tid < 16 && pf.st_out[1] != nullptr) {
+      for (int spin = 0; spin < (1 << 20); ++spin) {
+        if (__hip_atomic_load(kread, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (tid == 0) __hip_atomic_store(kread, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (put_state is defined in the front-end scope: the same transposition, inlined here)
+      const int D = H * GK, d0 = h * GK + 8 * oct;
+      u32x4 row[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = T + j;
+        row[j] = (T >= 4 || e >= 4) ? keep_tl[j] : (e == 1 ? keep_h[0] : (e == 2 ? keep_h[1] : keep_h[2]));
+      }
+      const unsigned int r0w[4] = {row[0].x, row[0].y, row[0].z, row[0].w}, r1w[4] = {row[1].x, row[1].y, row[1].z, row[1].w};
+      const unsigned int r2w[4] = {row[2].x, row[2].y, row[2].z, row[2].w}, r3w[4] = {row[3].x, row[3].y, row[3].z, row[3].w};
+      u32x4* op = (u32x4*)(pf.st_out[1] + ((size_t)b * D + d0) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned int lo01 = __builtin_amdgcn_perm(r1w[i], r0w[i], 0x05040100u), lo23 = __builtin_amdgcn_perm(r3w[i], r2w[i], 0x05040100u);
+        const unsigned int hi01 = __builtin_amdgcn_perm(r1w[i], r0w[i], 0x07060302u), hi23 = __builtin_amdgcn_perm(r3w[i], r2w[i], 0x07060302u);
+        op[i] = u32x4{lo01, lo23, hi01, hi23};
+      }
+    }
+  }
+  if (done != nullptr) {
     // publish: every thread's (device-scope) record stores have been acknowledged, then one thread raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) atomicAdd(done, 1u);
   }
 }
 
@@ -738,7 +815,8 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  gdn_chunk_prepare_body<F8, FUSED, false>(smem, (int)blockIdx.x, (int)blockIdx.y, q, k, g, beta, pf, ws, T, H, t_seg0, nt_seg, l2norm, nullptr);
+  gdn_chunk_prepare_body<F8, FUSED, false, 0>(smem, (int)blockIdx.x, (int)blockIdx.y, q, k, g, beta, pf, ws, T, H, t_seg0, nt_seg, l2norm, nullptr,
+                                              nullptr);
 }
 
 // ==================================================================================================
@@ -950,9 +1028,11 @@ __device__ __forceinline__ void wait_vm() {
 // (counted in headdone[bh], which it also clears): the area is all-zero between launches -- the caller zeroes it once.
 constexpr int SYNC_HEAD_WORDS = 16;       // flag words per head (chunks of the call: the single-launch form takes <= 16)
 struct ScanSync {
-  unsigned int* flags = nullptr;
+  unsigned int* flags = nullptr;            // flags[16 bh + c]: pre-pass workgroups of (bh, chunk c) that have published
   unsigned int* headdone = nullptr;
+  unsigned int* kread = nullptr;            // kread[bh]: the q side of chunk 0 has read the old conv state of k (split pre-pass)
   int BH = 0;
+  unsigned int nprod = 1;                   // pre-pass workgroups per chunk (2: split into a k side and a q side)
 };
 __device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
   const unsigned int* p = sy.flags + bh * SYNC_HEAD_WORDS + (lane < nt_seg ? lane : 0);   // lane c watches chunk c: one 64-byte line per head
@@ -961,7 +1041,7 @@ __device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, in
   // hanging the device
   for (int spin = 0; spin < (1 << 20); ++spin) {
     const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_amdgcn_ballot_w64(v == 0u) == 0ull) break;
+    if (__builtin_amdgcn_ballot_w64(v != sy.nprod) == 0ull) break;
     __builtin_amdgcn_s_sleep(4);
   }
 }
@@ -1746,21 +1826,30 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
 constexpr int SINGLE_THREADS = 64 * (2 * 2 + SCAN_NL + SCAN_NV);
 constexpr int SINGLE_MAX_BLOCKS = 256;
 constexpr int G_SYNC_BYTES = IVL_GDN_SYNC_BYTES;   // flags: 16 words per head (<= 32 heads) at 0; headdone: words at 2048
-static_assert(G_SYNC_BYTES >= 2048 + 4 * 32, "sync area layout");
-template <bool F8>
+static_assert(G_SYNC_BYTES >= 2048 + 4 * 32 + 4 * 32, "sync area layout");   // ... kread: 32 words behind headdone
+// SPLIT (room for twice the pre-pass workgroups: 2 nt_seg BH + 8 BH <= 256): blocks [0, nt_seg BH) are the k sides (the chain
+// the scan waits for: first to be dispatched), [nt_seg BH, 2 nt_seg BH) the q sides of the chunks.
+template <bool F8, bool SPLIT>
 __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
     PrepFused pf, unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv, const void* h0, int h0_dtype, void* ht,
     int ht_dtype, int T, int H, int BH, int nt_seg, float scale, ScanSync sy) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int nprep = nt_seg * BH;
+  const int nside = nt_seg * BH, nprep = SPLIT ? 2 * nside : nside;
   int id = (int)blockIdx.x;
   if (id < nprep) {
-    if (threadIdx.x >= 512) return;
+    if (threadIdx.x >= (SPLIT ? 576 : 512)) return;
+    const bool qside = SPLIT && id >= nside;
+    if (qside) id -= nside;
     int bh, ci;
     if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
     else { bh = id / nt_seg; ci = id % nt_seg; }
-    gdn_chunk_prepare_body<F8, true, true>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1,
-                                     sy.flags + bh * SYNC_HEAD_WORDS + ci);
+    unsigned int* done = sy.flags + bh * SYNC_HEAD_WORDS + ci;
+    if constexpr (!SPLIT)
+      gdn_chunk_prepare_body<F8, true, true, 0>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, nullptr);
+    else if (!qside)
+      gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, sy.kread + bh);
+    else
+      gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, sy.kread + bh);
   } else {
     id -= nprep;
     gdn_chunk_scan_body<2, F8, true, true>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, 0, nt_seg, scale, sy);
@@ -1769,7 +1858,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
 
 #ifdef IVL_TRACE
 int g_scan_ncw = 0;                        // developer knob (trace build only): force 2 or 4 compute waves per scan workgroup
-int g_gdn_single = 1;                      // developer knob (trace build only): 0 = never take the single-launch form
+int g_gdn_single = 1;                      // developer knob (trace build only): 0 = never take the single-launch form, 2 = never split the pre-pass
 #endif
 
 }  // namespace ivl
@@ -1796,8 +1885,11 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
     scan_set_attr<4, false, false>(); scan_set_attr<2, false, false>(); scan_set_attr<4, true, false>(); scan_set_attr<2, true, false>();
     scan_set_attr<4, false, true>(); scan_set_attr<2, false, true>(); scan_set_attr<4, true, true>(); scan_set_attr<2, true, true>();
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false>, attr, scan_lds_bytes(2, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true>, attr, scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, false>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, true>, attr, scan_lds_bytes(2, false));
+    const int lds8 = scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES;
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, false>, attr, lds8);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, true>, attr, lds8);
   });
 }
 
@@ -1839,11 +1931,19 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   single = single && g_gdn_single != 0;
 #endif
   if (single) {
+    bool split = 2 * NT * B * H + 8 * B * H <= SINGLE_MAX_BLOCKS;
+#ifdef IVL_TRACE
+    split = split && g_gdn_single != 2;
+#endif
     ScanSync sy;
-    sy.flags = sync; sy.headdone = sync + 512; sy.BH = B * H;
+    sy.flags = sync; sy.headdone = sync + 512; sy.kread = sync + 512 + 32; sy.BH = B * H; sy.nprod = split ? 2u : 1u;
     const int lds = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
-    hipLaunchKernelGGL((gdn_chunk_single_kernel<F8>), dim3(NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb, (bf16_t*)o, sv,
-                       h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
+    if (split)
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, true>), dim3(2 * NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb,
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
+    else
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, false>), dim3(NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb,
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
     return check_launch("ivl_gdn_chunk_fused_fwd(single launch)");
   }
   for (int c0 = 0; c0 < NT; c0 += segc) {
