@@ -243,7 +243,8 @@ __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x
 //   1 = the k side: conv + l2norm of k ONLY (all eight waves, runs of two tokens), gates, L, T = (I + L)^-1, w, Tu, Kd -- the
 //       chain the scan waits for, without the q half of the front end and without Aqk / q_hat;
 //   2 = the q side: conv + l2norm of q and k (as ROLE 0), q_hat, Aqk.
-// With ROLE != 0 the gate step P1a runs on a ninth wave (wave 8, which leaves behind B1) instead of behind wave 1's conv work.
+// (The gate step P1a stays behind wave 1's conv work: a ninth wave for it starts ~2,000 cycles after wave 0 -- the waves of a
+// workgroup are launched one after the other -- and arrived at B1 later than wave 1 does with both jobs.)
 // The conv state of k is read by BOTH workgroups of chunk 0 and written (possibly in place) by the k side: the q side raises
 // `kread` once its loads of the old state have returned, the k side writes the new state at its very end, behind that word.
 template <bool F8, bool FUSED, bool DEV, int ROLE>
@@ -284,7 +285,6 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   //         here at all (round 3: it belongs to the scan's V waves)
   const int oct = tid & 15;
   const bool is_k = KONLY || wave_u >= 4;            // fused: the array this wave converts (wave-uniform)
-  const bool front = ROLE == 0 || wave_u < 8;        // (ROLE != 0: wave 8 only runs P1a)
   // SIMD s hosts waves s and s + 4.  Three pieces of single-wave work sit in front of B1: the conv-state hand-over of q (the
   // threads that hold rows 0-3: wave 0), of k (wave 6: the k runs are rotated by 8) and the gate / cumsum step P1a (wave 1):
   // three different SIMDs.
@@ -292,7 +292,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   constexpr int NQK = FUSED ? (KONLY ? 2 : 4) : 2;   // rows per thread (fused: of ONE array)
   u32x4 kraw[NQK], qraw[NQK];                        // fused: only the wave's own array is populated
   bf16_t braw[NQK];
-  constexpr int P1A_WAVE = ROLE == 0 ? 1 : 8;
+  constexpr int P1A_WAVE = 1;
   u32x4 keep_tl[4], keep_h[3];                       // ROLE 1: the k conv-state hand-over is written at the end (see above)
   // the P1a wave also fetches the chunk's gate inputs here (consumed in P1a, behind its conv work: requested there they were
   // a memory round trip of their own on the wave every other one waits for at B1)
@@ -310,6 +310,40 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       p1_b = bf2f(beta[tok1]);
     }
   }
+  // ---- P1a (one wave): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta -------------
+  // Fused front end: called BEHIND the issue of the wave's loads and IN FRONT of its conv work -- the gate inputs were requested
+  // first and return first (in order), so the step runs while the wave's row loads are still in flight instead of making
+  // wave 1 the last arrival at B1 by its whole length (~1,800 cycles).
+  auto p1a = [&]() {
+    float g_ld, b_ld;
+    if constexpr (FUSED) {                           // g = -exp(A_log) softplus(a + dt_bias), beta = bf16(sigmoid(b)) (std:1293-1294)
+      const float av = p1_g + p1_dt;
+      const float sp = av > 20.f ? av : log1pf(expf(av));
+      g_ld = -expf(p1_A) * sp;
+      b_ld = bf2f(f2bf(sigmoid_exact_(p1_b)));
+    } else {
+      g_ld = p1_g;
+      b_ld = p1_b;
+    }
+    float gv = lane < nvalid ? g_ld : 0.f;
+    const float bv = lane < nvalid ? b_ld : 0.f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(gv, o, 64);
+      if (lane >= o) gv += up;
+    }
+    const float gl = __shfl(gv, nvalid - 1, 64);     // gamma at the last VALID token
+    const float e = __expf(gv);
+    s_gam[lane] = gv;
+    s_eg[lane] = e;
+    s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
+    s_beta[lane] = bv;                               // 0 for padded rows
+    if constexpr (DO_K) {
+      rec_st<DEV>((float*)(rec + R::EG) + lane, e);
+      rec_st<DEV>((bf16_t*)(rec + R::BETA) + lane, f2bf(bv));     // the scan's V waves scale v with it (beta is a bf16 value: exact)
+      if (lane == 0) rec_st<DEV>(rec + R::EGL, __expf(gl));
+    }
+  };
   auto qk_row = [&](int rr) { return FUSED ? NQK * r0 + rr : r0 + 32 * rr; };
   if constexpr (!FUSED) {
 #pragma unroll
@@ -398,7 +432,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       }
     };
     const bool own_state = t0 == 0;                                    // this workgroup holds time 0
-    if (front) {
+    {
       const int a = is_k ? 1 : 0;                                      // 0: q, 1: k (wave-uniform)
       u32x4 xr[NQK + 3], wt[4];
       const int col = (is_k ? pf.col_k : pf.col_q) + h * GK + 8 * oct;
@@ -425,6 +459,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       } else if (second_run) {
         history_load(st4, pf.st_in[a]);
       }
+      if (wave_u == P1A_WAVE) p1a();                                   // (consumes the wave's OLDEST loads only)
       if (is_k) {
 #pragma unroll
         for (int rr = 0; rr < NQK; ++rr) braw[rr] = f2bf(sigmoid_exact_(bf2f(bin[rr])));     // beta = bf16(sigmoid(b)) (std:1293)
@@ -456,36 +491,8 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       IVL_TOUT(9, tf1 - tf0); IVL_TOUT(10, tf2 - tf1);
     }
   }
-  // ---- P1a (one wave): g -> chunk-local inclusive cumsum -> e^gamma, decay to the chunk end; beta -------------
-  if (wave_u == P1A_WAVE) {
-    float g_ld, b_ld;
-    if constexpr (FUSED) {                           // g = -exp(A_log) softplus(a + dt_bias), beta = bf16(sigmoid(b)) (std:1293-1294)
-      const float av = p1_g + p1_dt;
-      const float sp = av > 20.f ? av : log1pf(expf(av));
-      g_ld = -expf(p1_A) * sp;
-      b_ld = bf2f(f2bf(sigmoid_exact_(p1_b)));
-    } else {
-      g_ld = p1_g;
-      b_ld = p1_b;
-    }
-    float gv = lane < nvalid ? g_ld : 0.f;
-    const float bv = lane < nvalid ? b_ld : 0.f;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const float up = __shfl_up(gv, o, 64);
-      if (lane >= o) gv += up;
-    }
-    const float gl = __shfl(gv, nvalid - 1, 64);     // gamma at the last VALID token
-    const float e = __expf(gv);
-    s_gam[lane] = gv;
-    s_eg[lane] = e;
-    s_dec[lane] = __expf(gl - gv);                   // e^{gamma_last - gamma_t}
-    s_beta[lane] = bv;                               // 0 for padded rows
-    if constexpr (DO_K) {
-      rec_st<DEV>((float*)(rec + R::EG) + lane, e);
-      rec_st<DEV>((bf16_t*)(rec + R::BETA) + lane, f2bf(bv));     // the scan's V waves scale v with it (beta is a bf16 value: exact)
-      if (lane == 0) rec_st<DEV>(rec + R::EGL, __expf(gl));
-    }
+  if constexpr (!FUSED) {
+    if (wave_u == P1A_WAVE) p1a();
   }
   // ---- P1b: l2norm -> k_hat, q_hat (bf16);  bf16(beta k_hat) -------------------------------------------------
   auto norm_row = [&](u32x4 xv, int row, bool ok, float* f) {        // f[0..7] = x / |x| (fp32), 0 for a padded row
@@ -513,7 +520,6 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   };
 #pragma unroll
   for (int rr = 0; rr < NQK; ++rr) {
-    if (!front) break;
     const int row = qk_row(rr);
     const bool ok = row < nvalid;
     float f[8];
@@ -530,7 +536,6 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   IVL_TOUT(15, tb1 - tp0); IVL_TOUT_AT(448, 29, tb1 - tp0); IVL_TOUT_AT(64, 30, tb1 - tp0);
   __syncthreads();                                   // B1
   IVL_T(tp1);
-  if (ROLE != 0 && wave_u == 8) return;              // the P1a wave is done (later barriers count the live waves only)
 
   // Copy-out of the two operands that are plain re-orderings of the LDS tiles, piece `idx` of 2048:
   //   [0,1024)    QH : piece (block 4m+s, g, i) = q_hat[16m+i][32s + {4g..4g+3, 16+4g..+3}]
@@ -620,6 +625,12 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       __syncthreads();
       if (tid == 0) atomicAdd(done, 1u);
     }
+#ifdef IVL_TRACE
+    if (ivl_trace_buf != nullptr && tid == 0) {       // q side: last start (47), last publish (45)
+      atomicMax((unsigned long long*)ivl_trace_buf + 45, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      atomicMax((unsigned long long*)ivl_trace_buf + 47, rt_p0);
+    }
+#endif
     return;
   }
   __syncthreads();                                   // B2: s_L complete
@@ -774,9 +785,20 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
 #endif
   IVL_TOUT(0, tp0); IVL_TOUT(1, tp1 - tp0); IVL_TOUT(2, tp2 - tp1); IVL_TOUT(3, tp3a - tp2); IVL_TOUT(4, tp3b - tp3a);
   IVL_TOUT(5, tp3 - tp3b); IVL_TOUT(6, tp4 - tp3); IVL_TOUT(7, tp4);
+  IVL_T(tq1);
+  if (done != nullptr) {
+    // publish: every thread's (device-scope) record stores have been acknowledged, then one thread raises the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IVL_T(tq2);
+    __syncthreads();
+    IVL_T(tq3);
+    if (tid == 0) atomicAdd(done, 1u);
+    IVL_TOUT(49, tq1 - tp4); IVL_TOUT(50, tq2 - tq1); IVL_TOUT(51, tq3 - tq2);
+  }
   if constexpr (ROLE == 1) {
     // the new conv state of k (chunk 0, the sixteen threads that read the old one): the q side's workgroup has read the old
-    // state too once `kread` is up (bounded wait, as scan_wait_records) -- cleared again for the next launch
+    // state too once `kread` is up (bounded wait, as scan_wait_records) -- cleared again for the next launch.  Behind the
+    // publish: the scan does not read the conv state, and the device-scope load of the word is a full memory round trip
     if (t0 == 0 && tid < 16 && pf.st_out[1] != nullptr) {
       for (int spin = 0; spin < (1 << 20); ++spin) {
         if (__hip_atomic_load(kread, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
@@ -802,12 +824,12 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
       }
     }
   }
-  if (done != nullptr) {
-    // publish: every thread's (device-scope) record stores have been acknowledged, then one thread raises the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) atomicAdd(done, 1u);
+#ifdef IVL_TRACE
+  if (ivl_trace_buf != nullptr && tid == 0) {         // last publish (46), last start (48)
+    atomicMax((unsigned long long*)ivl_trace_buf + 46, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    atomicMax((unsigned long long*)ivl_trace_buf + 48, rt_p0);
   }
+#endif
 }
 
 template <bool F8, bool FUSED>
@@ -1837,7 +1859,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
   const int nside = nt_seg * BH, nprep = SPLIT ? 2 * nside : nside;
   int id = (int)blockIdx.x;
   if (id < nprep) {
-    if (threadIdx.x >= (SPLIT ? 576 : 512)) return;
+    if (threadIdx.x >= 512) return;
     const bool qside = SPLIT && id >= nside;
     if (qside) id -= nside;
     int bh, ci;

@@ -50,6 +50,8 @@ for it in range(3):
     if t[42]:
         print(f"    single launch, ns after the first pre-pass workgroup's start: scan workgroup 0 starts {(t[41]-t[26]) * 10} | last pre-pass end {(t[27]-t[26]) * 10} "
               f"| flags seen {(t[42]-t[26]) * 10} | PA {(t[43]-t[26]) * 10} | scan end {(t[44]-t[26]) * 10}")
+        print(f"      pre-pass workgroup 0 (k side of chunk 0), cycles: conv-state wait + write {t[49]} | store drain {t[50]} | barrier {t[51]}")
+        print(f"      k side: last start {(t[48]-t[26]) * 10} last publish {(t[46]-t[26]) * 10} | q side: last start {(t[47]-t[26]) * 10 if t[47] else None} last publish {(t[45]-t[26]) * 10 if t[45] else None}")
     print(f"    scan: total {t[22]-t[16]} | loop {t[20]} (per chunk: sb cvt+publish {t[24]//NT} | T wait {t[17]//NT} | phase A + vn publish {t[18]//NT} | M wait {t[23]//NT} | phase B {t[19]//NT}) "
           f"| state store {t[21]} | prepare end -> scan start {t[16]-t[7]} "
           f"| scan realtime ticks {t[25]} -> {(t[22]-t[16]) / max(t[25], 1) * 100:.0f} MHz if the tick is 100 MHz")
