@@ -637,29 +637,35 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
   IVL_T(tp2);
 
   // ---- P3: T = (I + L)^-1 in place (waves 0-3); waves 4-7 finish the copy-outs meanwhile -----------------------
-  // level 0: 16x16 diagonal block `wave` by column-parallel substitution, the solution vector in registers:
-  //          lane j (every 16-lane group redundantly) owns column j of the inverse (forward substitution, row by row).
+  // level 0: the 16x16 diagonal block `wave`, D = I + N with N strictly lower (N^16 = 0):
+  //          D^-1 = (I - N)(I + N^2)(I + N^4)(I + N^8), eight 16x16x16 products on v_mfma_f32_16x16x4_f32 (fp32 operands).
+  //          A product takes its left factor in the A layout (lane (g, j): M[j][4g + s]) and its right factor in the B layout
+  //          (M[4g + s][j]), which is also the layout of a result; the A layout of M is the result layout of M^T, so the
+  //          squarings carry both M (N2C, N4C) and M^T (N2A, N4A, N8A: "M in the A layout") along.  (A row-by-row forward
+  //          substitution on 16 lanes was ~2,500 cycles of dependent FMAs; this is ~600.)
   if (wave_u < 4) {
     const int bb = 16 * wave_u;
-    float x[16];
-    x[0] = l15 == 0 ? 1.f : 0.f;
+    const f32x4 NA = *(const f32x4*)(s_L + (bb + l15) * P_LDF + bb + 4 * g4);
+    f32x4 NB;
 #pragma unroll
-    for (int i = 1; i < 16; ++i) {                   // row i of (I + L) x = e_j: four partial dot products in flight
-      float pz[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 4; ++s) NB[s] = s_L[(bb + 4 * g4 + s) * P_LDF + bb + l15];
+    auto mm = [](const f32x4 A, const f32x4 B, f32x4 C) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (4 * c >= i) continue;
-        const f32x4 lr = *(const f32x4*)(s_L + (bb + i) * P_LDF + bb + 4 * c);   // wave-uniform address: broadcast
+      for (int s = 0; s < 4; ++s) C = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], B[s], C, 0, 0, 0);
+      return C;
+    };
+    const f32x4 Z0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 N2C = mm(NA, NB, Z0), N2A = mm(NB, NA, Z0);
+    const f32x4 N4C = mm(N2A, N2C, Z0), N4A = mm(N2C, N2A, Z0);
+    const f32x4 N8A = mm(N4C, N4A, Z0);
+    f32x4 Rr;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (4 * c + e < i) pz[c] = fmaf(lr[e], x[4 * c + e], pz[c]);
-      }
-      x[i] = (i == l15 ? 1.f : 0.f) - ((pz[0] + pz[1]) + (pz[2] + pz[3]));
-    }
-    if (lane < 16) {
+    for (int s = 0; s < 4; ++s) Rr[s] = (4 * g4 + s == l15 ? 1.f : 0.f) - NB[s];      // I - N
+    Rr = mm(N2A, Rr, Rr);
+    Rr = mm(N4A, Rr, Rr);
+    Rr = mm(N8A, Rr, Rr);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s_L[(bb + i) * P_LDF + bb + l15] = x[i];
-    }
+    for (int r = 0; r < 4; ++r) s_L[(bb + 4 * g4 + r) * P_LDF + bb + l15] = Rr[r];
   } else if (ROLE == 0) {
     const int t2 = tid - 256;                        // 0..255
 #pragma unroll
