@@ -721,40 +721,44 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
     static_assert(PF_H1 == 5, "wait_older counts PF_H1 instructions");
     IVL_TVAR(tl_k); IVL_TVAR(tl_kw); IVL_TVAR(tl_v); IVL_TVAR(tl_vw);
     IVL_T(tl_s0);
-    fetch(0, 0); fetch(0, 1);
-    fetch(1, 0); fetch(1, 1);
-    bool newest = false;
-    IVL_T(tl_s1);
-    wait_older(false);
-    IVL_T(tl_s2);
-    seg_barrier();                              // tiles 0 and 1 are in LDS: the compute waves start
-    IVL_T(tl_s3);
-    IVL_TOUT_AT(512, 41, tl_s0 - tr_start); IVL_TOUT_AT(512, 43, tl_s1 - tl_s0); IVL_TOUT_AT(512, 46, tl_s2 - tl_s1); IVL_TOUT_AT(512, 48, tl_s3 - tl_s2);
-    IVL_TOUT_AT(640, 49, tl_s1 - tl_s0); IVL_TOUT_AT(640, 54, tl_s2 - tl_s1);
+    // ONE loop for the start-up and the steady state (each part of `fetch` is instantiated once per loader kind: the kernel
+    // is larger than the 64 KB instruction cache two CUs share, and the start-up ran through cold code -- ~6,000 cycles before
+    // the first DMA instruction).  Iterations j = -2, -1 issue what the steady state would have issued two tiles earlier,
+    // without the barriers; the compute waves start behind the start-up barrier, which needs K(0) only (behind j = -2).
     // K(i): stage free from segment 2i - 4, complete before barrier 2i - 1: issued in segments 2i - 4 | 2i - 3, waited for in 2i - 1.
     // V(i): free from 2i - 3, complete before barrier 2i: issued in segments 2i - 3 | 2i - 2, waited for in 2i.
+    bool newest = false;
 #pragma nounroll
-    for (int j = 0; j < n; ++j) {
+    for (int j = -2; j < n; ++j) {
       IVL_T(tl0);
       if (is_k) {
         newest = fetch(j + 2, 0);               // K(j+2) over K(j-1), last read before barrier 2j - 1
       } else {
-        wait_older(newest);                     // V(j) has landed (part 0 of V(j+1) may still fly)
-        if (j >= 1) fetch(j + 1, 1);
+        if (j >= 0) wait_older(newest);         // V(j) has landed (part 0 of V(j+1) may still fly)
+        if (j >= -1) fetch(j + 1, 1);
       }
       IVL_T(tl1);
-      seg_barrier();                            // sigma = 2j
+      if (j >= 0) seg_barrier();                // sigma = 2j
       IVL_T(tl2);
       if (is_k) {
-        wait_older(newest);                     // K(j+1) has landed
+        if (j >= 0) wait_older(newest);         // K(j+1) has landed
         fetch(j + 2, 1);
       } else {
         newest = fetch(j + 2, 0);               // V(j+2) over V(j-1), last read before barrier 2j
       }
       IVL_T(tl3);
-      seg_barrier();                            // sigma = 2j + 1
+      if (j >= 0) seg_barrier();                // sigma = 2j + 1
       IVL_T(tl4);
-      IVL_TACC(tl_k, tl1, tl0); IVL_TACC(tl_kw, tl2, tl1); IVL_TACC(tl_v, tl3, tl2); IVL_TACC(tl_vw, tl4, tl3);
+      if (j == -2) {
+        if (is_k) wait_older(false);            // K(0) is in LDS (K(1), V(0) follow: before barriers 1 and 0)
+        IVL_T(tl_s2);
+        seg_barrier();                          // the compute waves start
+        IVL_TOUT_AT(512, 41, tl_s0 - tr_start); IVL_TOUT_AT(512, 43, tl_s2 - tl_s0);
+        IVL_TOUT_AT(640, 49, tl_s2 - tl_s0);
+      }
+      if (j >= 0) {
+        IVL_TACC(tl_k, tl1, tl0); IVL_TACC(tl_kw, tl2, tl1); IVL_TACC(tl_v, tl3, tl2); IVL_TACC(tl_vw, tl4, tl3);
+      }
     }
     seg_barrier();                              // sigma = 2n
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -783,10 +787,21 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
       for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qp + 16 * kd + 8 * hi5);
     }
     if (p.rcos != nullptr) {
+      // fused M-RoPE of the query tile: the sixteen table pieces of the lane's row are requested together with its eight query
+      // pieces (one memory round trip), then rotated in registers -- while the loaders bring the first key tile in
       const long long row_off = ((long long)b * p.T + min(row, p.T - 1)) * SWA_D;
+      const long long plane = (long long)p.B * p.T * SWA_D;
+      u32x4 c1[4], n1[4], c2[4], n2[4];
 #pragma unroll
-      for (int kd = 0; kd < 4; ++kd)
-        rope_pair(qf[kd], qf[kd + 4], p.rcos, p.rsin, (long long)p.B * p.T * SWA_D, row_off, 16 * kd + 8 * hi5, p.rs0, p.rs1);
+      for (int kd = 0; kd < 4; ++kd) {
+        const int c0 = 16 * kd + 8 * hi5;
+        const int sec = c0 < p.rs0 ? 0 : (c0 < p.rs0 + p.rs1 ? 1 : 2);
+        const long long off = sec * plane + row_off + c0;
+        c1[kd] = *(const u32x4*)(p.rcos + off); n1[kd] = *(const u32x4*)(p.rsin + off);
+        c2[kd] = *(const u32x4*)(p.rcos + off + 64); n2[kd] = *(const u32x4*)(p.rsin + off + 64);
+      }
+#pragma unroll
+      for (int kd = 0; kd < 4; ++kd) rope_apply(qf[kd], qf[kd + 4], c1[kd], n1[kd], c2[kd], n2[kd]);
     }
     if (!row_ok) {
 #pragma unroll
@@ -903,7 +918,7 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
 
     IVL_T(tr_loop);
     IVL_TVAR(tr_a); IVL_TVAR(tr_b); IVL_TVAR(tr_wa); IVL_TVAR(tr_wb);
-    seg_barrier();                              // tiles 0 and 1 are in LDS
+    seg_barrier();                              // K(0) is in LDS
     {
       // the second-dispatched half loses every VALU arbitration against its older SIMD partner: static priority evens it
       if (kh == 1) __builtin_amdgcn_s_setprio(1);
@@ -1484,6 +1499,9 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   // (one split) every q-tile would rotate the new keys it visits again (a 4096-token call over a full ring: each key tile
   // ~16 times, through registers instead of the LDS-DMA path) -- both cases rotate ONCE in a pre-pass; only short single-split
   // calls keep the rotation in the kernel (one launch less).
+  // (measured again in round 3 with the tables requested in one round trip: the rotation of a 128-row query tile is ~700
+  // VALU instructions per lane -- every product and sum is rounded to bf16 like the reference's -- and costs each of the eight
+  // splits ~8,000 cycles that also slow its loader waves down: 34.7 vs 31.6 us per call at the step shape.)
   if (prefill && p.rcos != nullptr && (nsplit > 1 || a->T >= 4 * PF_QT)) {
     // rotate q and the call's keys once, into the workspace behind the partials (see swa_rope_prepass_kernel)
     // rounded up to 16 bytes: the pre-pass, the attention kernel and the ring append move q_rot / k_rot as 16-byte vectors

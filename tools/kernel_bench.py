@@ -22,8 +22,12 @@ def main():
     ap.add_argument("--window", type=int, default=4096)
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--lib", default=None, help="A/B timing against another build of the library (developer use)")
     args = ap.parse_args()
     import infinitevl_amd
+    if args.lib:
+        from infinitevl_amd import _lib
+        _lib.load(args.lib)
     infinitevl_amd.load_library()
     dev = torch.device("cuda", 0)
     res = bench.kernel_timings(dev, args.chunk, args.window, only=args.only)

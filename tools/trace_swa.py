@@ -51,7 +51,7 @@ for it in range(3):
         print(f"      key half 1 per tile: A (QK + row max) {t[50]//n} + wait {t[51]//n} | B (exps + PV) {t[52]//n} + wait {t[53]//n}")
         print(f"      loader wave 8 (K) per tile: issue DMA {t[55]//n} + wait {t[56]//n} | vmcnt {t[59]//n} + wait {t[60]//n}")
         print(f"      loader wave 10 (V) per tile: vmcnt {t[57]//n} + wait {t[58]//n} | issue DMA {t[62]//n} + wait {t[63]//n}")
-        print(f"      start-up, loader wave 8 (K): setup {t[41]} | issue tiles 0, 1: {t[43]} | vmcnt(0) {t[46]} | barrier wait {t[48]} || wave 10 (V): issue {t[49]} | vmcnt(0) {t[54]}")
+        print(f"      start-up, loader wave 8 (K): setup {t[41]} | tiles 0, 1 issued and landed: {t[43]} || wave 10 (V) at the start-up barrier: {t[49]}")
         print(f"      launch on the 100 MHz clock: first workgroup start -> last start {(t[31]-t[29]) * 10} ns -> last end {(t[30]-t[29]) * 10} ns")
         dec = lambda v: f"{v >> 24} cycles ({(v >> 16) & 255} tiles, split {(v >> 8) & 255}, q-tile {v & 255})"
         print(f"      slowest workgroup: {dec(t[44])} | fastest: {dec(t[45])}")
