@@ -102,7 +102,7 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  *   workgroups and wait on flags in this area, which the launch itself clears again (all-zero between launches, so the
  *   call is replayable from a hipGraph).  Results are bit-identical to the two-launch form.
  * ------------------------------------------------------------------------------------------- */
-#define IVL_GDN_SYNC_BYTES 4096
+#define IVL_GDN_SYNC_BYTES 16384
 IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
                             const void* wq, const void* wk, const void* wv, const void* sq_in, const void* sk_in,
                             const void* sv_in, void* sq_out, void* sk_out, void* sv_out, const float* A_log,

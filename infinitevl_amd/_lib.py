@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 
 IVL_BF16, IVL_F32, IVL_FP8_E4M3 = 0, 2, 3
 IVL_OK = 0
-IVL_GDN_SYNC_BYTES = 4096
+IVL_GDN_SYNC_BYTES = 16384
 IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
 
 EXPORTED_SYMBOLS = (
