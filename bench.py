@@ -315,13 +315,23 @@ def kernel_timings(device, chunk, window, only=None, live_prefill=None, live_dec
                                                 v_cache=rings[i % NSW][1], pos_dev=pos_dev, append=True), 96, "decode", 9, "hbm",
         1024.0 * window)
     x1, r1 = rn(B, 1, 2048), rn(B, 1, 2048)
-    add("add_rmsnorm(decode token)", lambda i: ops.add_rmsnorm(x1, r1, wh, 1e-6), 96, "decode", 73, "hbm", 4.0 * 2048 * 2)
-    # decode-step projections (M = 1 weight streams; outside SURVEY.md section 8's rows, listed for the decode leg)
-    for nm, N_, K_, per in (("gdn in-proj", 12320, 2048, 27), ("mlp gate|up", 22016, 2048, 36),
-                            ("mlp down", 2048, 11008, 36), ("gdn o_proj", 2048, 4096, 27), ("lm_head", 151936, 2048, 1)):
-        w_, x_ = rn(N_, K_), rn(1, 1, K_)
-        add(f"decode linear {nm} [{N_}x{K_}]", lambda i, w_=w_, x_=x_: ops.linear(x_, w_), 48, "decode", per, "hbm",
-            2.0 * N_ * K_ + 2.0 * (N_ + K_))
+    # (round 3: the 72 per-layer norms of a decode token run in the prologue of the projection that follows them -- only the
+    # final norm is still a launch of its own)
+    add("add_rmsnorm(decode token)", lambda i: ops.add_rmsnorm(x1, r1, wh, 1e-6), 96, "decode", 1, "hbm", 4.0 * 2048 * 2)
+    # decode-step projections (M = 1 weight streams; outside SURVEY.md section 8's rows, listed for the decode leg); "norm +":
+    # (residual add +) RMSNorm in the kernel's prologue (ivl_norm_linear_small_m_fwd)
+    for nm, N_, K_, per, norm in (("norm + gdn in-proj", 12320, 2048, 27, True), ("norm + mlp gate|up (SwiGLU)", 11008, 2048, 36, True),
+                                  ("mlp down", 2048, 11008, 36, False), ("gdn o_proj", 2048, 4096, 27, False),
+                                  ("lm_head", 151936, 2048, 1, False)):
+        glu = "SwiGLU" in nm
+        w_, x_ = rn(2 * N_ if glu else N_, K_), rn(1, 1, K_)
+        if norm:
+            fn = (lambda i, w_=w_, x_=x_: ops.linear_swiglu(ops.PreNorm(x_, r1, wh, 1e-6), w_)) if glu else \
+                 (lambda i, w_=w_, x_=x_: ops.linear(ops.PreNorm(x_, r1, wh, 1e-6), w_))
+        else:
+            fn = lambda i, w_=w_, x_=x_: ops.linear(x_, w_)      # noqa: E731
+        add(f"decode linear {nm} [{(2 * N_ if glu else N_)}x{K_}]", fn, 48, "decode", per, "hbm",
+            2.0 * (2 * N_ if glu else N_) * K_ + 2.0 * (N_ + K_))
         del w_, x_
     del projs, css
     # batched streams (8 sequences per GPU in one call): the same kernels with 8x the work per launch

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 6
+#define IVL_ABI_VERSION 7
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -298,6 +298,15 @@ IVL_API int ivl_linear_small_m_fwd(const void* x, const void* w, const void* bia
  * = ivl_linear_small_m_fwd on the fused weight followed by ivl_silu_mul_fwd, bit for bit.  bias [2I] or NULL. */
 IVL_API int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, const void* bias, void* y, int M, int I, int K,
                                   void* stream);
+
+/* (Residual add +) RMSNorm in the prologue of the decode step's projection: ivl_add_rmsnorm_fwd followed by
+ * ivl_linear_small_m_fwd (glu == 0) or ivl_linear_swiglu_small_m_fwd (glu != 0, N = I), bit for bit, in ONE launch --
+ * the decoder layer's input_layernorm -> q|k|v / GDN in-projection, post_attention_layernorm -> gate|up, and the final
+ * norm -> lm_head (std:1350-1429, 1573, 2091-2092) at q_len == 1: 73 one-row norm launches per token disappear.
+ *   h = bf16(x + residual) (residual NULL: h = x; else written to h_out [M,K]);  xn = bf16(norm_weight * bf16(h * rstd(h)));
+ *   y = linear(xn).  x, residual, h_out bf16 [M,K]; norm_weight bf16 [K]; K <= 4096; the rest as the two entry points above. */
+IVL_API int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, const void* norm_weight, float eps, void* h_out,
+                                const void* w, const void* bias, void* y, int M, int N, int K, int glu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "ivl_gdn_prologue_fwd", "ivl_rmsnorm_swish_gate_strided_fwd", "ivl_mrope_strided_fwd",
     "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd", "ivl_linear_small_m_fwd",
     "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd", "ivl_rope_tables_fwd",
-    "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd",
+    "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd", "ivl_norm_linear_small_m_fwd",
 )
 
 
@@ -122,6 +122,8 @@ def load(path: str = None) -> ctypes.CDLL:
                                             vp, i, i, i, i, f, vp]
     lib.ivl_linear_swiglu_small_m_fwd.restype = i
     lib.ivl_linear_swiglu_small_m_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.ivl_norm_linear_small_m_fwd.restype = i
+    lib.ivl_norm_linear_small_m_fwd.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, i, i, i, i, vp]
     _lib = lib
     return lib
 

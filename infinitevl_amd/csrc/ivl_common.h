@@ -36,6 +36,15 @@ __device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ float bflo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
+// eight bf16 of a 16-byte piece <-> fp32
+__device__ __forceinline__ void unpack8(u32x4 v, float* f) {
+  f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+  f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+
 __device__ __forceinline__ float h2f_bits(unsigned short h) {
   _Float16 x;
   __builtin_memcpy(&x, &h, 2);

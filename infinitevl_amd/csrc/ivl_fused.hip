@@ -36,13 +36,6 @@ struct ProParams {
   int B, T, H, conv_blocks, apply_silu;
 };
 
-__device__ __forceinline__ void unpack8(u32x4 v, float* f) {
-  f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
-  f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
-}
-__device__ __forceinline__ u32x4 pack8(const float* f) {
-  return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
-}
 
 template <int FC_TCH>      // >= 3 (see above)
 __global__ __launch_bounds__(256) void gdn_prologue_kernel(ProParams p) {

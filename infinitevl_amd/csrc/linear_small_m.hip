@@ -9,6 +9,13 @@
 // GLU variant (the SwiGLU MLP, std:945): W is the fused gate|up weight [2I,K]; a wave owns rows n and I+n and writes
 // act[n] = bf16(bf16(silu(bf16(gate_n))) * bf16(up_n)) -- the gate costs one exp per OUTPUT element.  (Forming the
 // gate on the input side of down_proj instead repeats it in every wave: measured 2.49 -> 2.88 ms per decode token.)
+//
+// NORM variant (round 3): the RMSNorm in front of the projection -- (residual add +) Qwen2RMSNorm, 73 one-row launches of
+// ivl_add_rmsnorm_fwd per decode token, each ~4.2 us inside the token's graph: 15 % of the token -- runs in the prologue of
+// the weight stream.  Every workgroup forms the normalised rows itself (M x K <= 4 x 4096 elements: 8 KB of L2-resident
+// input per row, the same thread -> element mapping, summation order and rounding points as add_rmsnorm_kernel: the rows
+// are bit-identical to that kernel's) into LDS while its first weight pieces are in flight, and reads x from there;
+// workgroup 0 also writes the new residual stream h = bf16(x + residual).
 #include "ivl_common.h"
 
 namespace ivl {
@@ -23,16 +30,26 @@ __device__ __forceinline__ float dot8(u32x4 a, u32x4 b, float acc) {
 
 constexpr int LSM_U = 4;          // 16-byte pieces per lane per row in flight
 
+struct NormArgs {
+  const bf16_t* residual;          // NULL: plain norm of x
+  const bf16_t* weight;            // RMSNorm weight [K]
+  bf16_t* h_out;                   // new residual stream (written by workgroup 0 when residual != NULL)
+  float eps;
+};
+constexpr int LSM_NORM_KMAX = 4096;
+
 // N = number of OUTPUT columns (GLU: I; the weight then has 2N rows)
-template <int RPW, int M, bool GLU>
+template <int RPW, int M, bool GLU, bool NORM>
 __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
-                                                            int N, int K) {
+                                                            int N, int K, NormArgs na) {
   constexpr int NR = GLU ? 2 * RPW : RPW;          // weight rows per wave
+  __shared__ __attribute__((aligned(16))) u32x4 s_x[NORM ? M * (LSM_NORM_KMAX / 8) : 1];
+  __shared__ float s_part[NORM ? M : 1][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;
-  if (row0 >= N) return;
   const int nchunk = K >> 3;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  if (!NORM && row0 >= N) return;                  // (NORM: every wave takes part in the barriers; its rows are clamped, its stores guarded)
   const u32x4* wrow[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -45,17 +62,88 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __res
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 
+  // NORM: the rows' pieces (x, residual, norm weight) are requested FIRST -- vector-memory results return in issue order, so
+  // requested behind the weight pieces they would only arrive behind the whole weight stream of the wave -- then the weight
+  // pieces; norm_rows (every wave: workgroup barriers inside) then runs while the weights are in flight.
+  const int tid = threadIdx.x;
+  u32x4 xraw[NORM ? M : 1][2], rraw[NORM ? M : 1][2], wraw[2];
+  if constexpr (NORM) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int v = min(tid + it * 256, nchunk - 1);
+      wraw[it] = *(const u32x4*)(na.weight + v * 8);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        xraw[m][it] = *(const u32x4*)(x + (size_t)m * K + v * 8);
+        rraw[m][it] = na.residual != nullptr ? *(const u32x4*)(na.residual + (size_t)m * K + v * 8) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  auto norm_rows = [&]() {
+    float hv[M][2][8];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float ss = 0.f;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int v = tid + it * 256;
+        if (v < nchunk) {
+          unpack8(xraw[m][it], hv[m][it]);
+          if (na.residual != nullptr) {
+            float rv[8];
+            unpack8(rraw[m][it], rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hv[m][it][i] = bf_round(hv[m][it][i] + rv[i]);
+            if (blockIdx.x == 0) *(u32x4*)(na.h_out + (size_t)m * K + v * 8) = pack8(hv[m][it]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss = fmaf(hv[m][it][i], hv[m][it][i], ss);
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) s_part[m][wave] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float tot = s_part[m][0] + s_part[m][1] + s_part[m][2] + s_part[m][3];
+      const float rstd = rsqrtf(tot / (float)K + na.eps);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int v = tid + it * 256;
+        if (v < nchunk) {
+          float wv8[8], o8[8];
+          unpack8(wraw[it], wv8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o8[i] = wv8[i] * bf_round(hv[m][it][i] * rstd);
+          s_x[m * (LSM_NORM_KMAX / 8) + v] = pack8(o8);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  bool first = true;
   for (int c0 = lane; c0 < nchunk; c0 += 64 * LSM_U) {
     u32x4 wv[LSM_U][NR], xv[LSM_U][M];
+#pragma unroll
+    for (int u = 0; u < LSM_U; ++u) {
+      const int cc = min(c0 + 64 * u, nchunk - 1);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) wv[u][r] = __builtin_nontemporal_load(wrow[r] + cc);
+    }
+    if constexpr (NORM) {
+      if (first) norm_rows();                      // (the loop trip count is workgroup-uniform)
+      first = false;
+    }
 #pragma unroll
     for (int u = 0; u < LSM_U; ++u) {
       const int c = c0 + 64 * u;
       const int cc = min(c, nchunk - 1);
 #pragma unroll
-      for (int r = 0; r < NR; ++r) wv[u][r] = __builtin_nontemporal_load(wrow[r] + cc);
-#pragma unroll
       for (int m = 0; m < M; ++m) {
-        const u32x4 xl = *((const u32x4*)(x + (size_t)m * K) + cc);
+        u32x4 xl;
+        if constexpr (NORM) xl = s_x[m * (LSM_NORM_KMAX / 8) + cc];
+        else xl = *((const u32x4*)(x + (size_t)m * K) + cc);
         xv[u][m] = c < nchunk ? xl : u32x4{0u, 0u, 0u, 0u};      // pieces past the row end contribute nothing
       }
     }
@@ -85,19 +173,21 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __res
     }
 }
 
-template <int RPW, bool GLU>
-static void launch_lsm(const bf16_t* x, const bf16_t* w, const bf16_t* bias, bf16_t* y, int M, int N, int K, hipStream_t st) {
+template <int RPW, bool GLU, bool NORM>
+static void launch_lsm(const bf16_t* x, const bf16_t* w, const bf16_t* bias, bf16_t* y, int M, int N, int K, const NormArgs& na,
+                       hipStream_t st) {
   const int rows_per_wg = 4 * RPW;
   dim3 grid((N + rows_per_wg - 1) / rows_per_wg);
   switch (M) {
-    case 1: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 1, GLU>), grid, dim3(256), 0, st, x, w, bias, y, N, K); break;
-    case 2: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 2, GLU>), grid, dim3(256), 0, st, x, w, bias, y, N, K); break;
-    case 3: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 3, GLU>), grid, dim3(256), 0, st, x, w, bias, y, N, K); break;
-    default: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 4, GLU>), grid, dim3(256), 0, st, x, w, bias, y, N, K); break;
+    case 1: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 1, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+    case 2: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 2, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+    case 3: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 3, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+    default: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 4, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
   }
 }
 
-static int lsm_dispatch(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool glu,
+template <bool NORM>
+static int lsm_dispatch(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool glu, const NormArgs& na,
                         void* stream, const char* who) {
   IVL_REQUIRE(x && w && y, IVL_ERR_INVALID_ARG, "%s: NULL pointer", who);
   IVL_REQUIRE(M >= 1 && M <= 4, IVL_ERR_UNSUPPORTED, "%s: M=%d (built for 1..4 rows; use a GEMM)", who, M);
@@ -107,12 +197,12 @@ static int lsm_dispatch(const void* x, const void* w, const void* bias, void* y,
   bf16_t* yp = (bf16_t*)y;
   // rows per wave: enough workgroups to cover the chip (>= ~2 per CU) before amortising the x reads over more rows
   if (glu) {
-    if (N >= 4096) launch_lsm<2, true>(xp, wp, bp, yp, M, N, K, st);       // 4 weight rows per wave
-    else launch_lsm<1, true>(xp, wp, bp, yp, M, N, K, st);
+    if (N >= 4096) launch_lsm<2, true, NORM>(xp, wp, bp, yp, M, N, K, na, st);       // 4 weight rows per wave
+    else launch_lsm<1, true, NORM>(xp, wp, bp, yp, M, N, K, na, st);
   } else {
-    if (N >= 8192) launch_lsm<4, false>(xp, wp, bp, yp, M, N, K, st);
-    else if (N >= 4096) launch_lsm<2, false>(xp, wp, bp, yp, M, N, K, st);
-    else launch_lsm<1, false>(xp, wp, bp, yp, M, N, K, st);
+    if (N >= 8192) launch_lsm<4, false, NORM>(xp, wp, bp, yp, M, N, K, na, st);
+    else if (N >= 4096) launch_lsm<2, false, NORM>(xp, wp, bp, yp, M, N, K, na, st);
+    else launch_lsm<1, false, NORM>(xp, wp, bp, yp, M, N, K, na, st);
   }
   return check_launch(who);
 }
@@ -123,10 +213,21 @@ using namespace ivl;
 
 extern "C" int ivl_linear_small_m_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K,
                                       void* stream) {
-  return lsm_dispatch(x, w, bias, y, M, N, K, false, stream, "ivl_linear_small_m_fwd");
+  return lsm_dispatch<false>(x, w, bias, y, M, N, K, false, NormArgs{}, stream, "ivl_linear_small_m_fwd");
 }
 
 extern "C" int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, const void* bias, void* y, int M, int I,
                                              int K, void* stream) {
-  return lsm_dispatch(x, w_gate_up, bias, y, M, I, K, true, stream, "ivl_linear_swiglu_small_m_fwd");
+  return lsm_dispatch<false>(x, w_gate_up, bias, y, M, I, K, true, NormArgs{}, stream, "ivl_linear_swiglu_small_m_fwd");
+}
+
+extern "C" int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, const void* norm_weight, float eps, void* h_out,
+                                           const void* w, const void* bias, void* y, int M, int N, int K, int glu, void* stream) {
+  IVL_REQUIRE(norm_weight != nullptr, IVL_ERR_INVALID_ARG, "ivl_norm_linear_small_m_fwd: NULL norm weight");
+  IVL_REQUIRE(residual == nullptr || h_out != nullptr, IVL_ERR_INVALID_ARG, "ivl_norm_linear_small_m_fwd: residual needs h_out");
+  IVL_REQUIRE(K <= LSM_NORM_KMAX, IVL_ERR_UNSUPPORTED, "ivl_norm_linear_small_m_fwd: K=%d (the normalised rows are staged in LDS: K <= %d)", K,
+              LSM_NORM_KMAX);
+  NormArgs na;
+  na.residual = (const bf16_t*)residual; na.weight = (const bf16_t*)norm_weight; na.h_out = (bf16_t*)h_out; na.eps = eps;
+  return lsm_dispatch<true>(x, w, bias, y, M, glu ? N : N, K, glu != 0, na, stream, "ivl_norm_linear_small_m_fwd");
 }

@@ -123,6 +123,8 @@ class InfiniteVLTextMLP(nn.Module):
         if (self._fused_w is not None and x.is_cuda and x.dtype == torch.bfloat16
                 and self.gate_proj.weight.data_ptr() == self._fused_w.data_ptr()):
             return ops.linear(ops.linear_swiglu(x, self._fused_w), self.down_proj.weight)
+        if isinstance(x, ops.PreNorm):
+            x = x.materialize()
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
@@ -229,12 +231,25 @@ class InfiniteVLTextStack(nn.Module):
         # The residual add that ends a decoder layer (std:1422) is fused into the NEXT layer's input RMSNorm
         # (one add+norm launch instead of add, norm): `resid` is the residual stream, `pend` the not-yet-added
         # MLP output of the previous layer.
+        # Decode steps (<= 4 rows): the norms are not launched here -- a PreNorm travels into the mixer / MLP and runs in the
+        # prologue of their first weight-stream kernel (ops.PreNorm).
+        small = ops._PRENORM and inputs_embeds.is_cuda and inputs_embeds.dtype == torch.bfloat16 and B * T <= 4
+
+        def norm(mod, x, residual):
+            """(new residual stream, normalised input or its PreNorm)"""
+            if small:
+                pn = ops.PreNorm(x, residual, mod.weight, mod.variance_epsilon)
+                return pn.h, pn
+            if residual is None:
+                return x, mod(x)
+            return mod.add_and_norm(x, residual)
+
         resid, pend = inputs_embeds, None
         for layer in self.layers:                                                    # std:1555-1571
             if pend is None:
-                y = layer.input_layernorm(resid)
+                resid, y = norm(layer.input_layernorm, resid, None)
             else:
-                resid, y = layer.input_layernorm.add_and_norm(pend, resid)
+                resid, y = norm(layer.input_layernorm, pend, resid)
             if layer_hooks is not None:
                 layer_hooks[0](layer.self_attn.layer_idx)
             attn, _ = layer.self_attn(hidden_states=y, position_ids=position_ids, past_key_values=past_key_values,
@@ -242,8 +257,12 @@ class InfiniteVLTextStack(nn.Module):
                                       position_embeddings=position_embeddings)
             if layer_hooks is not None:
                 layer_hooks[1](layer.self_attn.layer_idx)
-            resid, y = layer.post_attention_layernorm.add_and_norm(attn, resid)
+            if isinstance(y, ops.PreNorm) and not y.done:
+                y.materialize()                          # (a mixer path that never asked for its input: keep the residual valid)
+            resid, y = norm(layer.post_attention_layernorm, attn, resid)
             pend = layer.mlp(y)
+            if isinstance(y, ops.PreNorm) and not y.done:
+                y.materialize()
         if pend is None:
             h = self.norm(resid)
         else:

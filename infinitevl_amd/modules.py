@@ -105,6 +105,8 @@ class InfiniteVLSelfAttention(nn.Module):
                 output_attentions: bool = False, use_cache: bool = False,
                 cache_position: Optional[torch.LongTensor] = None,
                 position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, **kwargs):
+        if isinstance(hidden_states, ops.PreNorm) and not self._fused_ok(hidden_states):
+            hidden_states = hidden_states.materialize()        # (a not-yet-launched input norm: only the fused q|k|v GEMV runs it)
         bsz, q_len, _ = hidden_states.size()
         cos, sin = position_embeddings
         # projections stay time-major [B,T,H,d]: the kernels take strides, no transpose/copy (std:1047-1054)
@@ -308,6 +310,8 @@ class GatedDeltaNet(nn.Module):
         layer = past_key_values.layers[self.layer_idx] if past_key_values is not None else None
         if self._fused_ok(hidden_states, layer):
             return self._forward_fused(hidden_states, past_key_values, layer, cache_position, mode)
+        if isinstance(hidden_states, ops.PreNorm):
+            hidden_states = hidden_states.materialize()
         use_cache = past_key_values is not None
         native = isinstance(layer, StaticLinearLayerPrealloc)
         prev_conv, recurrent_state = (None, None, None), None

@@ -516,6 +516,63 @@ def add_rmsnorm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch
     return y, (h if h is not None else x)
 
 
+_PRENORM = True            # tests switch it off to compare the fused norm + projection launches with the separate ones
+
+
+class PreNorm:
+    """A (residual add +) RMSNorm that has NOT been launched: the decoder stack hands it to a mixer / MLP in place of the
+    normalised input during a decode step (<= 4 rows), and `linear` / `linear_swiglu` run it in the prologue of their
+    weight-stream kernel (ivl_norm_linear_small_m_fwd: same arithmetic as ivl_add_rmsnorm_fwd, one launch less per norm --
+    72 per token).  `h` is the new residual stream x + residual (x itself without a residual): allocated here, written by
+    whichever kernel ends up running the norm.  Anything else that needs the normalised tensor calls materialize()."""
+
+    def __init__(self, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float):
+        self.x = x if x.is_contiguous() else x.contiguous()
+        self.residual = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
+        self.weight = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        self.eps = float(eps)
+        self.h = torch.empty_like(self.x) if residual is not None else self.x
+        self.shape, self.dtype, self.device, self.is_cuda = self.x.shape, self.x.dtype, self.x.device, self.x.is_cuda
+        self._y = None
+        self.done = False                      # the norm has run (h is valid)
+
+    def size(self, *a):
+        return self.x.size(*a)
+
+    def dim(self):
+        return self.x.dim()
+
+    def numel(self):
+        return self.x.numel()
+
+    def materialize(self) -> torch.Tensor:
+        if self._y is None:
+            N = self.x.shape[-1]
+            self._y = torch.empty_like(self.x)
+            _lib.check(_lib.load().ivl_add_rmsnorm_fwd(_p(self.x), _p(self.residual), _p(self.weight), _p(self._y),
+                                                       _p(self.h) if self.residual is not None else None,
+                                                       self.x.numel() // N, N, self.eps, _stream(self.x)))
+            self.done = True
+        return self._y
+
+
+def _prenorm_linear(pn: "PreNorm", weight: torch.Tensor, bias: Optional[torch.Tensor], glu: bool) -> Optional[torch.Tensor]:
+    """The fused launch when it applies (decode step, bf16, K <= 4096), else None."""
+    K = weight.shape[-1]
+    rows = pn.numel() // K if K else 0
+    if not (pn.is_cuda and 1 <= rows <= 4 and pn.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+            and weight.is_contiguous() and K % 8 == 0 and K <= 4096 and pn.shape[-1] == K and pn._y is None
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))):
+        return None
+    N = weight.shape[0] // 2 if glu else weight.shape[0]
+    y = torch.empty(*pn.shape[:-1], N, dtype=torch.bfloat16, device=pn.device)
+    _lib.check(_lib.load().ivl_norm_linear_small_m_fwd(
+        _p(pn.x), _p(pn.residual), _p(pn.weight), pn.eps, _p(pn.h) if pn.residual is not None else None,
+        _p(weight), _p(bias) if bias is not None else None, _p(y), rows, N, K, 1 if glu else 0, _stream(pn.x)))
+    pn.done = True
+    return y
+
+
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     """SwiGLU gate on a fused gate|up projection [..., 2I] -> [..., I]."""
     _need_gpu(gate_up)
@@ -530,6 +587,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """nn.Linear forward.  A single-token decode step (<= 4 rows) is a pure weight stream and goes through
     ivl_linear_small_m_fwd; longer calls are stock library GEMMs (hipBLASLt / rocBLAS through torch), which
     SURVEY.md 8(d) keeps outside the hot path."""
+    if isinstance(x, PreNorm):
+        y = _prenorm_linear(x, weight, bias, False)
+        if y is not None:
+            return y
+        x = x.materialize()
     K = weight.shape[-1]
     rows = x.numel() // K if K else 0
     if (x.is_cuda and 1 <= rows <= 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
@@ -547,6 +609,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 def linear_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor) -> torch.Tensor:
     """silu(gate_proj(x)) * up_proj(x) with the fused gate|up weight [2I, K] (std:945).  Decode steps (<= 4 rows)
     apply the gate in the epilogue of the weight-stream kernel; longer calls are a library GEMM + silu_mul."""
+    if isinstance(x, PreNorm):
+        y = _prenorm_linear(x, w_gate_up, None, True)
+        if y is not None:
+            return y
+        x = x.materialize()
     K = w_gate_up.shape[-1]
     I = w_gate_up.shape[0] // 2
     rows = x.numel() // K

@@ -1375,7 +1375,8 @@ def test_decode_step_uses_weight_stream_and_matches_gemm_path():
     try:
         for forced in (False, True):
             if forced:
-                ops.linear = lambda x, w, b=None: torch.nn.functional.linear(x, w, b)
+                ops.linear = lambda x, w, b=None: torch.nn.functional.linear(          # noqa: E731
+                    x.materialize() if isinstance(x, ops.PreNorm) else x, w, b)
             with torch.no_grad():
                 stack(inputs_embeds=x0, position_ids=pid0, past_key_values=caches[forced], logits_to_keep=1)
                 h, lg = stack(inputs_embeds=x1, position_ids=pid1, past_key_values=caches[forced], logits_to_keep=1)
@@ -1627,6 +1628,73 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
         for a, b_ in zip(so, so_ref):
             assert torch.equal(a, b_)
     assert int(area.view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,glu,res", [(1, 12320, 2048, False, True), (1, 2560, 2048, False, True), (1, 11008, 2048, True, True),
+                                           (4, 4096, 2048, False, False), (3, 1000, 4096, True, True), (2, 151936, 2048, False, True)])
+def test_norm_linear_small_m_equals_the_separate_launches(M, N, K, glu, res):
+    """ivl_norm_linear_small_m_fwd (the RMSNorm in the prologue of the decode step's weight stream) must equal
+    ivl_add_rmsnorm_fwd followed by ivl_linear_small_m_fwd / ivl_linear_swiglu_small_m_fwd bit for bit: projection output and
+    the new residual stream (std:1350-1429 at q_len == 1)."""
+    from infinitevl_amd import ops
+    g_ = torch.Generator(device=DEV).manual_seed(M * 7 + N)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    x, r = rn(1, M, K), (rn(1, M, K) if res else None)
+    nw = bf(1.0 + 0.1 * torch.randn(K, device=DEV, generator=g_))
+    W = rn(2 * N if glu else N, K) * 0.05
+    bias = None if glu else rn(N)
+    y_sep, h_sep = ops.add_rmsnorm(x, r, nw, 1e-6)
+    out_sep = ops.linear_swiglu(y_sep, W) if glu else ops.linear(y_sep, W, bias)
+    pn = ops.PreNorm(x, r, nw, 1e-6)
+    out = ops.linear_swiglu(pn, W) if glu else ops.linear(pn, W, bias)
+    assert pn.done and pn._y is None, "the fused launch must have been taken"
+    assert torch.equal(out, out_sep)
+    assert torch.equal(pn.h, h_sep)
+
+
+def test_decode_step_with_norms_in_the_projection_prologue_is_bit_identical():
+    """The decode step of the full-width stack with the 72 per-layer norms run inside the projection kernels (ops.PreNorm) must
+    produce the logits and caches of the step with separate norm launches, bit for bit, eagerly and from the captured graph."""
+    from infinitevl_amd import ops
+    from infinitevl_amd.harness import GraphedDecode, InfiniteVLTextConfig, InfiniteVLTextStack
+    cfg = InfiniteVLTextConfig(num_hidden_layers=8)
+    stack = InfiniteVLTextStack(cfg).to(DEV).to(torch.bfloat16).init_weights_(seed=3).fuse_()
+    g_ = torch.Generator(device=DEV).manual_seed(5)
+    x = bf(torch.randn(1, 200, cfg.hidden_size, device=DEV, generator=g_) * 0.5)
+    caches = []
+    for flag in (False, True):
+        ops._PRENORM = flag
+        try:
+            c = stack.allocate_inference_cache(1, zero_init=True)
+            stack(inputs_embeds=x, past_key_values=c, logits_to_keep=1)
+            lgs = []
+            tok = torch.tensor([[17]], device=DEV)
+            for it in range(6):
+                _, lg = stack(input_ids=tok, past_key_values=c, logits_to_keep=1)
+                lgs.append(lg.clone())
+                tok = lg[:, -1].argmax(-1, keepdim=True)
+            caches.append((c, lgs))
+        finally:
+            ops._PRENORM = True
+    for a, b_ in zip(caches[0][1], caches[1][1]):
+        assert torch.equal(a, b_)
+    for la, lb in zip(caches[0][0].layers, caches[1][0].layers):
+        for ta, tb in zip(la.carried_tensors(), lb.carried_tensors()):
+            assert torch.equal(ta, tb)
+    # graph replay of the fused form continues bit-identically to eager stepping of the separate form
+    gd = GraphedDecode(stack, caches[1][0], 1)
+    gd.token.fill_(23)
+    tok = torch.tensor([[23]], device=DEV)
+    ops._PRENORM = False
+    try:
+        for it in range(3):
+            _, lg_ref = stack(input_ids=tok, past_key_values=caches[0][0], logits_to_keep=1)
+            tok = lg_ref[:, -1].argmax(-1, keepdim=True)
+            got = gd.step()
+            assert torch.equal(gd.logits.reshape(-1), lg_ref.reshape(-1)), it
+            assert torch.equal(got.reshape(-1), tok.reshape(-1))
+    finally:
+        ops._PRENORM = True
 
 
 def test_rope_tables_kernel_matches_the_eager_chain():
