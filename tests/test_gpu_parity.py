@@ -1555,14 +1555,11 @@ def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("B,T,hist", [(1, 256, True), (1, 512, True), (1, 64, False), (1, 300, True), (1, 7, True),
-                                      # long calls: scan workgroups first, records awaited chunk by chunk; two workspace segments
-                                      (1, 1000, True), (1, 4300, True)])
+@pytest.mark.parametrize("B,T,hist", [(1, 256, True), (1, 512, True), (1, 64, False), (1, 300, True), (1, 7, True)])
 def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
     """ivl_gdn_chunk_fused_fwd with a sync area (pre-pass and scan workgroups of ONE launch, the scan side waiting on flags) must
     equal the two-launch form bit for bit -- outputs, final state, conv states -- call after call (the launch clears its own
-    flags: the area is all-zero afterwards) and when replayed from a hipGraph.  Small grids: split pre-pass (k side / q side),
-    all records awaited at the start; long calls: the pre-pass streams beside the serial scan."""
+    flags: the area is all-zero afterwards) and when replayed from a hipGraph."""
     from infinitevl_amd import ops
     H, K, V = 16, 128, 256
     Dq, Dk, Dv = H * K, H * K, H * V
@@ -1587,7 +1584,7 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
     # the two-launch reference of every input set first, then the single-launch calls back to back: a record line left in
     # some L2 by an earlier launch would belong to different inputs
     sets, refs = [], []
-    for it in range(10 if T <= 512 else 3):
+    for it in range(10):
         st = (rn(B, T, ld), [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)],
               bf(torch.randn(B, H, K, V, device=DEV, generator=g_) * 0.1) if hist else None)
         sets.append(st)
