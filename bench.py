@@ -734,7 +734,7 @@ def main():
             out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                               for k, v in kernels.items()}
             out["hot_path_ms_per_step"] = sum(call_ms(v) * v["launches_per_step"] for v in prefill_kernels.values())
-            out["hot_path_ms_per_step_live"] = sum(v["ms"] * v["launches_per_step"] for v in prefill_kernels.values())
+            out["hot_path_ms_per_step_microbench"] = sum(v["ms"] * v["launches_per_step"] for v in prefill_kernels.values())
             out["hot_path_ms_per_decode_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
                                                       for k, v in decode_kernels.items() if not k.startswith("decode linear"))
             out["decode_linear_ms_per_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
