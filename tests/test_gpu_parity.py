@@ -1555,8 +1555,9 @@ def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("B,T,hist", [(1, 256, True), (1, 512, True), (1, 64, False), (1, 300, True), (1, 7, True)])
-def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
+@pytest.mark.parametrize("B,T,hist,mma", [(1, 256, True, None), (1, 512, True, None), (1, 64, False, None), (1, 300, True, None),
+                                          (1, 7, True, None), (1, 256, True, "fp8_e4m3"), (2, 128, True, None)])
+def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma):
     """ivl_gdn_chunk_fused_fwd with a sync area (pre-pass and scan workgroups of ONE launch, the scan side waiting on flags) must
     equal the two-launch form bit for bit -- outputs, final state, conv states -- call after call (the launch clears its own
     flags: the area is all-zero afterwards) and when replayed from a hipGraph."""
@@ -1575,7 +1576,8 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist):
         ht = torch.zeros(B, H, K, V, dtype=torch.bfloat16, device=DEV)
         ops._GDN_SINGLE_LAUNCH = single
         try:
-            o = ops.gdn_chunk_fused(proj, cols, cw, so if hist else [None] * 3, so, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht)
+            o = ops.gdn_chunk_fused(proj, cols, cw, so if hist else [None] * 3, so, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht,
+                                    mma_dtype=mma)
         finally:
             ops._GDN_SINGLE_LAUNCH = True
         return o, ht, so
