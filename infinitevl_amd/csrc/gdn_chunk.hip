@@ -1,31 +1,32 @@
 // Gated DeltaNet, chunkwise form (chunk C = 64 tokens) for gfx950, K = 128, V = 256.
 // Replaces fla's six-kernel pipeline (fla:ops/gated_delta_rule/chunk.py:18-71: l2norm, cumsum, WY transform
-// wy_fast.py:114-238, state scan chunk_delta_h.py:32-124, output chunk_o.py:92-113) with two launches.
+// wy_fast.py:114-238, state scan chunk_delta_h.py:32-124, output chunk_o.py:92-113) -- and, for the fused call, the three
+// short convolutions and the gate glue in front of it -- with two launches, or ONE (gdn_chunk_single_kernel: both bodies in
+// one grid, the scan workgroups waiting on in-kernel flags; small grids).
 //
-//  (1) gdn_chunk_prepare_kernel -- chunk-PARALLEL, one 512-thread workgroup per (chunk, batch*head).  Everything
-//      that depends on q, k, g, beta only (the "K side"):
+//  (1) pre-pass (gdn_chunk_prepare_body) -- chunk-PARALLEL, one 512-thread workgroup per (chunk, batch*head).  Everything
+//      that depends on q, k, g, beta only (the "K side"; fused call: incl. conv + SiLU of q and k and the gate math):
 //        q_hat, k_hat = l2norm -> bf16;  gamma = cumsum(g);  L = tril(bf16(beta k_hat) k_hat^T, -1);
-//        Tw = (I+L)^-1 in fp32 (16x16 diagonal blocks by column-parallel substitution in registers, the rest by
-//        block elimination on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32, intermediates chained in registers);
-//        Tu = Tw * e^{gamma_i-gamma_j};  w = bf16(Tw) bf16(beta k_hat);  u = bf16(Tu) bf16(beta v);
-//        A = tril((q_hat k_hat^T) * Gamma).
-//      It leaves one 89 KB record per chunk holding the four A-operand matrices of the serial pass, already
-//      decayed / negated and stored as a sequence of 1 KB MFMA FRAGMENT BLOCKS (below), e^gamma, and u in the
-//      accumulator layout of the scan.
-//  (2) gdn_chunk_scan_kernel -- SERIAL over chunks.  One WAVE owns a 16-column slab of the state for all 128
+//        Tw = (I+L)^-1 in fp32 (16x16 diagonal blocks by a Neumann product, the rest by block elimination, all on the
+//        exact-fp32 MFMA v_mfma_f32_16x16x4_f32 with intermediates chained in registers);
+//        Tu = Tw * e^{gamma_i-gamma_j};  w = bf16(Tw) bf16(beta k_hat);  A = tril((q_hat k_hat^T) * Gamma).
+//      It leaves one 61 KB record per chunk: the four A-operand matrices of the serial pass, already decayed / negated and
+//      stored as a sequence of 1 KB MFMA FRAGMENT BLOCKS (below), e^gamma, beta and Tu.  In the single-launch form a chunk's
+//      pre-pass may be split over two workgroups (ROLE: k side | q side).
+//  (2) scan (gdn_chunk_scan_body) -- SERIAL over chunks.  One STATE WAVE owns a 16-column slab of the state for all 128
 //      rows: S[128 x 16] fp32 lives in 32 accumulator registers for the whole call and never visits LDS.  The
 //      MFMA C layout (lane = column, registers = rows) IS the B-operand layout of the next product once the
 //      contraction index is permuted inside each block of 32 (slot 8g+e <-> index 4g+e | 16+4g+(e-4)); the
-//      records are written with that permutation, so per chunk a wave runs
+//      records are written with that permutation, so per chunk
 //          v_new  = u - (w e^gamma) S            (16 MFMA, u as C input, S as B operand straight from the accumulators)
 //          S      = e^{gamma_L} S + (k_hat e^{gamma_L-gamma})^T v_new      (16 MFMA, v_new straight from accumulators)
-//          o^T    = scale ((S^T q_hat^T) e^gamma + v_new^T A^T)            (22 MFMA, transposed: 8-byte row stores)
-//      with no LDS traffic on the S -> v_new -> S chain.  A workgroup = 4 such compute waves (64 state columns)
-//      + 2 LOADER waves that do nothing but stream the chunks' operand images into LDS by LDS-DMA
-//      (global_load_lds_dwordx4, four 1 KB pieces per issue): the ~64 cycles a wave is held per DMA piece
-//      (the CU's 64 B/clk vector-memory path) never stall a wave that feeds the matrix pipe.  The image is split
-//      in two halves by phase (H1: Wn, q_hat, e^gamma, u slab; H2: Kd^T, Aqk), each double buffered and refilled
-//      right after its last reader's barrier: 1.5 chunks of prefetch distance with two barriers per chunk.
+//          o^T    = scale ((S^T q_hat^T) e^gamma + v_new^T A^T)            (22 MFMA: the OUTPUT WAVE of the pair)
+//      with no LDS traffic on the S -> v_new -> S chain.  A workgroup = NCW state waves + NCW output waves (32 or 64 state
+//      columns) + 4 LOADER waves that do nothing but stream the chunks' operand images into LDS by LDS-DMA
+//      (global_load_lds_dwordx4, counted vmcnt) + 4 V WAVES that form u = bf16(Tu (beta v)) -- with the conv + SiLU of v in
+//      the fused call -- one chunk ahead of the state waves (u does not depend on the state).  The image is split in two
+//      halves by phase (H1: Wn, q_hat, e^gamma; H2: Kd^T, Aqk), each double buffered and refilled right after its last
+//      reader's barrier: two barriers per chunk.
 //
 // Fragment block (v_mfma_f32_16x16x32_bf16): 16 rows x 32 contraction slots = 64 x 16 bytes, piece (g, i) at byte
 // 16 (16 g + i) holds row i, slots 8g..8g+7  <->  contraction indices 4g+e (e < 4), 16+4g+(e-4) (e >= 4).  A wave
