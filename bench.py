@@ -635,12 +635,39 @@ def main():
                 if r >= n_warm:
                     times3.append(time.perf_counter() - tA)
         mean3 = sum(times3) / len(times3)
+        # per-call kernel times of one more call of the same kind (torch.profiler activity records of the eager launches): the
+        # in-scope kernels of a 4096-token call over the full ring, grouped
+        kern3 = None
+        try:
+            import collections
+            from torch.profiler import ProfilerActivity, profile
+            start3 = cache.get_seq_length()
+            pid3 = torch.arange(start3, start3 + Tb, device=device)[None, None, :].expand(3, 1, Tb).contiguous()
+            torch.cuda.synchronize()
+            with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof3:
+                model(inputs_embeds=xb, position_ids=pid3, past_key_values=cache, logits_to_keep=1)
+                torch.cuda.synchronize()
+            grp = collections.defaultdict(lambda: [0.0, 0])
+            for ev in prof3.events():
+                if "cuda" not in str(ev.device_type).lower():
+                    continue
+                nm = ev.name
+                dur = float(ev.device_time if hasattr(ev, "device_time") else ev.cuda_time)
+                key = ("gdn_chunk (pre-pass + scan)" if "gdn_chunk" in nm else
+                       "swa (rope pre-pass + prefill + combine/append)" if ("swa_" in nm) else
+                       "gated norm / add+norm / SwiGLU gate / rope tables" if "ivl::" in nm else "library GEMMs and torch glue")
+                grp[key][0] += dur
+                grp[key][1] += 1
+            kern3 = {k: {"ms_per_call": round(v[0] * 1e-3, 4), "launches": v[1]} for k, v in grp.items()}
+        except Exception as e:                       # the breakdown is optional: never lose the leg over the profiler
+            kern3 = {"error": repr(e)}
         cfg3 = {"workload": "configs[3], one GPU's share: bulk prefill of one long sequence in 4096-token calls (eager launches) over a "
                             "full 4096-key ring with carried GDN state, starting at the context the streaming + decode legs reached",
                 "context_start": ctx0 + n_warm * Tb, "context_end": cache.get_seq_length(), "calls_timed": n_timed,
                 "tokens_per_call": Tb, "ms_per_call": mean3 * 1e3, "ms_per_call_min": min(times3) * 1e3,
                 "prefill_tok_s": Tb / mean3, "logits_finite": bool(torch.isfinite(lg3.float()).all()),
-                "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
+                "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                "kernel_ms_in_one_call": kern3}
         del xb
 
     # ---- configs[1] leg (rank 0, N=1; reported beside the headline, never mixed into `value`): one 4096-token
