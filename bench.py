@@ -106,7 +106,7 @@ def event_time_ms(fn, iters, stream):
 PROFILE_ROWS = {
     "gdn_chunk(prepare+scan)": [("ivl::gdn_chunk_prepare_kernel<false, false>", 32768), ("ivl::gdn_chunk_scan_kernel<2, false, false>", 98304)],
     # one launch at the step shape: 2 x 64 pre-pass (k side, q side) + 128 scan workgroups of 768 threads
-    "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_single_kernel<false, true>", 196608)],
+    "gdn_chunk_fused(convs+gates+prepare+scan)": [("ivl::gdn_chunk_single_kernel<false, 1>", 196608)],
     "swa_prefill(rope pre-pass + attention + combine with append)": [("ivl::swa_rope_prepass_kernel", 36864),
                                                                      ("ivl::swa_prefill_kernel", 196608),
                                                                      ("ivl::swa_combine_kernel<8, true>", 270336)],

@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void wait_vm() {
 // initial state), and their loader waves wait here for the flags of the head's records.  flags[16 bh + c] is raised by the
 // pre-pass workgroup of (chunk c, head bh) and cleared again by the LAST of the head's scan workgroups to have passed the wait
 // (counted in headdone[bh], which it also clears): the area is all-zero between launches -- the caller zeroes it once.
-constexpr int SYNC_HEAD_WORDS = 64;       // flag words per head: 256 bytes, so that no two heads' polls and atomics share a line
+constexpr int SYNC_HEAD_WORDS = 64;       // flag words per head: one per chunk of a workspace segment (G_SEG_CHUNKS)
 struct ScanSync {
   unsigned int* flags = nullptr;            // flags[16 bh + c]: pre-pass workgroups of (bh, chunk c) that have published
   unsigned int* headdone = nullptr;
@@ -1063,8 +1063,13 @@ struct ScanSync {
   int BH = 0;
   unsigned int nprod = 1;                   // pre-pass workgroups per chunk (2: split into a k side and a q side)
 };
+// the loader waves' wait at the start: every record of the call (small grids: the pre-pass workgroups all finish together), or,
+// for long calls (`progressive`), the records of chunks 0..2 (what the loaders request in front of the first chunk step) -- the
+// later chunks are then awaited by V wave 0, three chunks ahead of the state waves (scan_vwave)
+template <bool PROGRESSIVE>
 __device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
-  const unsigned int* p = sy.flags + bh * SYNC_HEAD_WORDS + (lane < nt_seg ? lane : 0);   // lane c watches chunk c: the head's own lines
+  const int nw = PROGRESSIVE ? (nt_seg < 3 ? nt_seg : 3) : nt_seg;         // (all at once: nt_seg <= 64 lanes)
+  const unsigned int* p = sy.flags + bh * SYNC_HEAD_WORDS + (lane < nw ? lane : 0);        // lane c watches chunk c
   // bounded (~0.1 s): the pre-pass workgroups have lower block ids and are dispatched first, so the wait ends within the
   // pre-pass's few microseconds; the bound only keeps a broken contract (a sync area shared by concurrent calls) from
   // hanging the device
@@ -1075,7 +1080,8 @@ __device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, in
   }
 }
 
-template <int L, int NCW, bool F8, bool SYNC>
+// SYNC: 0 = records from an earlier launch; 1 = single launch, all records awaited at the start; 2 = long calls (progressive)
+template <int L, int NCW, bool F8, int SYNC>
 __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned int lds0, unsigned int lane16, const ScanTouch& tc,
                                             int lane, const ScanSync& sy, int bh, bool trace_wg) {
   (void)trace_wg;
@@ -1095,13 +1101,13 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   };
   // issue order at the start: chunk 0's value tile, beta, Tu (the V waves' conversion + product of chunk 0 stand between their
   // arrival and the first chunk step) | H1(0) | chunk 1's set | H2(0) | H1(1) | touches
-  if constexpr (SYNC) {
+  if constexpr (SYNC != 0) {
     // single launch: the value tiles of chunks 0 and 1 do not come from the pre-pass -- requested before the wait
     static_assert(VD, "the single-launch form is built on the 32-column workgroup");
     constexpr int NB = L == 3 ? 1 : 0;
     load_vt<L, F8>(tc, 0, nt_seg, lane);
     load_vt<L, F8>(tc, 1, nt_seg, lane);
-    scan_wait_records(sy, bh, nt_seg, lane);
+    scan_wait_records<SYNC == 2>(sy, bh, nt_seg, lane);
 #ifdef IVL_TRACE
     if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[42] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -1193,9 +1199,10 @@ struct ScanV {
 
 constexpr int SCAN_NV = 4;                             // V waves per workgroup: one per 16-row time tile of the chunk
 
-template <int NCW, bool F8, bool VCONV>
+template <int NCW, bool F8, bool VCONV, int SYNC>
 __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* ws_bh, unsigned char* smem, int vw, int slab_wg,
-                                           int b, int h, int H, int T, int t_seg0, int nt_seg, int lane, bool trace_wg) {
+                                           int b, int h, int H, int T, int t_seg0, int nt_seg, int lane, bool trace_wg,
+                                           const ScanSync& sy, int bh) {
   using R = Rec<F8>;
   (void)trace_wg;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1438,10 +1445,33 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   IVL_TVAR(tv_wT); IVL_TVAR(tv_wM); IVL_TVAR(tv_mma); IVL_TVAR(tv_conv); IVL_TVAR(tv_x1); IVL_TVAR(tv_x2); IVL_TVAR(tv_x3);
   // iteration ci: [T] u(ci + 1) from set (ci + 1) & 1 [M] beta v of chunk ci + 2 from set ci & 1, then chunk ci + 3 -> set (ci + 1) & 1
   // (whose Tu the mma of this iteration has just consumed)
+  // Single-launch form: behind T(ci) the loader waves request beta (and, behind M(ci), Tu) of chunk ci + 3 from the record.
+  // V wave 0 -- which issues no other vector-memory instruction in this form -- arrives at T(ci) only once that record is
+  // published: the barrier carries the guarantee to the loaders (whose counted vmcnt bookkeeping a poll of their own would
+  // break).  The flag word is requested one chunk before it is looked at (a device-scope load is a full memory round trip).
+  unsigned int gate_val = 0;
+  auto gate_issue = [&](int c) {
+    if (c < nt_seg) gate_val = __hip_atomic_load(sy.flags + bh * SYNC_HEAD_WORDS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto gate_wait = [&](int c) {
+    if (c >= nt_seg) return;
+    unsigned int v = gate_val;
+    for (int spin = 0; v != sy.nprod && spin < (1 << 20); ++spin) {       // bounded like scan_wait_records
+      __builtin_amdgcn_s_sleep(4);
+      v = __hip_atomic_load(sy.flags + bh * SYNC_HEAD_WORDS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if constexpr (SYNC != 0) {
+    static_assert(VTILE, "the gate wave must have no vector-memory traffic of its own");
+    if (SYNC == 2 && vw == 0) gate_issue(3);
+  }
   auto body = [&](int ci, auto even_tag) {
     constexpr int E = decltype(even_tag)::value;                   // ci & 1
     using SA = std::integral_constant<int, E>;
     using SB = std::integral_constant<int, 1 - E>;
+    if constexpr (SYNC != 0) {
+      if (SYNC == 2 && vw == 0) { gate_wait(ci + 3); gate_issue(ci + 4); }
+    }
     IVL_T(ta);
     lds_barrier();                       // T(ci): beta v of chunk ci + 1 is staged
     IVL_T(tb);
@@ -1527,7 +1557,7 @@ __device__ __forceinline__ void scan_role(int w, int& role, int& idx) {
 
 // One scan workgroup: batch*head bx, column slab by.  SYNC (single-launch form): the records are written by pre-pass
 // workgroups of the SAME launch; `sync` -> ScanSync tells the loader waves where to wait for them.
-template <int NCW, bool F8, bool VCONV, bool SYNC>
+template <int NCW, bool F8, bool VCONV, int SYNC>
 __device__ __forceinline__ void gdn_chunk_scan_body(
     unsigned char* smem, const int bx, const int by,
     const unsigned char* __restrict__ ws, bf16_t* __restrict__ o, const ScanV& sv,
@@ -1575,7 +1605,7 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     return;
   }
   if (role == ROLE_V) {                                         // ---- V waves ----
-    scan_vwave<NCW, F8, VCONV>(sv, ws_bh, smem, ridx, by, b, h, H, T, t_seg0, nt_seg, lane, trace_wg);
+    scan_vwave<NCW, F8, VCONV, SYNC>(sv, ws_bh, smem, ridx, by, b, h, H, T, t_seg0, nt_seg, lane, trace_wg, sy, bh);
     return;
   }
   const int pair = ridx;
@@ -1588,16 +1618,20 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     // =========================== output wave ===========================
     frag_t fq[16];
     float egv[4];
-    lds_barrier();                       // PA
-    if constexpr (SYNC) {
-      // behind PA every loader wave of this workgroup has seen the head's flags: the last of the head's scan workgroups to
-      // get here clears them (and the count) for the next launch
+    // Once every wait of this workgroup on the head's flags lies behind it, the last of the head's scan workgroups to get here
+    // clears them (and the count) for the next launch.  (The returning atomic is a memory round trip: where all records are
+    // awaited at the start it sits here, behind PA -- every loader wave has seen the flags -- and costs nothing.)
+    auto flags_done = [&]() {
       if (pair == 0 && lane == 0) {
         if (atomicAdd(sy.headdone + bh, 1u) == (unsigned int)(16 / NCW - 1)) {
           for (int c = 0; c < nt_seg; ++c) __hip_atomic_store(sy.flags + bh * SYNC_HEAD_WORDS + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(sy.headdone + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    };
+    lds_barrier();                       // PA
+    if constexpr (SYNC != 0) {
+      if (SYNC == 1) flags_done();
     }
     lds_barrier();                       // P0
     lds_barrier();                       // P: H1(0) has landed
@@ -1670,6 +1704,9 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
       ivl_trace_buf[112 + 2 * pair] = ot_wT; ivl_trace_buf[113 + 2 * pair] = ot_wM;
     }
 #endif
+    if constexpr (SYNC != 0) {
+      if (SYNC == 2) flags_done();       // long calls: the last chunk's barriers have been passed
+    }
     lds_barrier();                       // F
     return;
   }
@@ -1841,7 +1878,7 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
     const void* h0, int h0_dtype, void* ht, int ht_dtype,
     int T, int H, int t_seg0, int nt_seg, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  gdn_chunk_scan_body<NCW, F8, VCONV, false>(smem, (int)blockIdx.x, (int)blockIdx.y, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0,
+  gdn_chunk_scan_body<NCW, F8, VCONV, 0>(smem, (int)blockIdx.x, (int)blockIdx.y, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0,
                                              nt_seg, scale, ScanSync{});
 }
 
@@ -1859,36 +1896,48 @@ constexpr int SYNC_MAX_HEADS = 32;
 static_assert(G_SYNC_BYTES >= 4 * (SYNC_MAX_HEADS * SYNC_HEAD_WORDS + 32 + 32), "sync area layout");   // ... kread: 32 words behind headdone
 // SPLIT (room for twice the pre-pass workgroups: 2 nt_seg BH + 8 BH <= 256): blocks [0, nt_seg BH) are the k sides (the chain
 // the scan waits for: first to be dispatched), [nt_seg BH, 2 nt_seg BH) the q sides of the chunks.
-template <bool F8, bool SPLIT>
+//
+// MODE 2, long calls (unsplit pre-pass): the 8 BH scan workgroups come FIRST and take one CU each (the host checks that the
+// device has at least twice as many), the pre-pass workgroups of the segment stream through the remaining CUs in chunk-major
+// order, and the scan consumes the records as they are published (V wave 0 gates every chunk step, three chunks ahead): the
+// pre-pass of a 4096-token call no longer runs in front of the 64 serial chunk steps but beside them.  A mode is a template
+// instance of its own: the step-shape kernel (MODE 1) carries none of the long-call code.
+// MODE: 0 = small grid, whole pre-pass per chunk; 1 = small grid, split pre-pass; 2 = long call
+template <bool F8, int MODE>
 __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
     PrepFused pf, unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv, const void* h0, int h0_dtype, void* ht,
-    int ht_dtype, int T, int H, int BH, int nt_seg, float scale, ScanSync sy) {
+    int ht_dtype, int T, int H, int BH, int t_seg0, int nt_seg, float scale, ScanSync sy) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int nside = nt_seg * BH, nprep = SPLIT ? 2 * nside : nside;
+  constexpr bool SPLIT = MODE == 1, SCAN_FIRST = MODE == 2;
+  const int nside = nt_seg * BH, nprep = SPLIT ? 2 * nside : nside, nscan = 8 * BH;
   int id = (int)blockIdx.x;
-  if (id < nprep) {
+  const bool is_scan = SCAN_FIRST ? id < nscan : id >= nprep;
+  if (!is_scan) {
     if (threadIdx.x >= 512) return;
+    if (SCAN_FIRST) id -= nscan;
     const bool qside = SPLIT && id >= nside;
     if (qside) id -= nside;
     int bh, ci;
-    if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
+    if (SCAN_FIRST) { ci = id / BH; bh = id % BH; }                   // chunk-major: the records appear in the order the scan needs them
+    else if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
     else { bh = id / nt_seg; ci = id % nt_seg; }
     unsigned int* done = sy.flags + bh * SYNC_HEAD_WORDS + ci;
     if constexpr (!SPLIT)
-      gdn_chunk_prepare_body<F8, true, true, 0>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, nullptr);
+      gdn_chunk_prepare_body<F8, true, true, 0>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, nullptr);
     else if (!qside)
-      gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, sy.kread + bh);
+      gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh);
     else
-      gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, 0, nt_seg, 1, done, sy.kread + bh);
+      gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh);
   } else {
-    id -= nprep;
-    gdn_chunk_scan_body<2, F8, true, true>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, 0, nt_seg, scale, sy);
+    if (!SCAN_FIRST) id -= nprep;
+    gdn_chunk_scan_body<2, F8, true, SCAN_FIRST ? 2 : 1>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0, nt_seg,
+                                                         scale, sy);
   }
 }
 
 #ifdef IVL_TRACE
 int g_scan_ncw = 0;                        // developer knob (trace build only): force 2 or 4 compute waves per scan workgroup
-int g_gdn_single = 1;                      // developer knob (trace build only): 0 = never take the single-launch form, 2 = never split the pre-pass
+int g_gdn_single = 1;                      // developer knob (trace build only): 0 = two launches always, 2 = never split the pre-pass, 3 = no overlapped long calls
 #endif
 
 }  // namespace ivl
@@ -1902,12 +1951,21 @@ static void scan_set_attr() {
   (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel<NCW, F8, VCONV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             scan_lds_bytes(NCW, F8));
 }
+static int g_cu_count[64];
+static int device_cu_count() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_cu_count[dev & 63];
+}
 // dynamic-LDS opt-in, once per device (hipFuncSetAttribute acts on the current device)
 static void gdn_chunk_init_device() {
   static std::once_flag once[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::call_once(once[dev & 63], [] {
+  std::call_once(once[dev & 63], [dev] {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    g_cu_count[dev & 63] = cus;
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false, false>, attr, P_BYTES);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, false>, attr, P_BYTES);
@@ -1915,11 +1973,13 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
     scan_set_attr<4, false, false>(); scan_set_attr<2, false, false>(); scan_set_attr<4, true, false>(); scan_set_attr<2, true, false>();
     scan_set_attr<4, false, true>(); scan_set_attr<2, false, true>(); scan_set_attr<4, true, true>(); scan_set_attr<2, true, true>();
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, false>, attr, scan_lds_bytes(2, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, true>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 0>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 1>, attr, scan_lds_bytes(2, false));
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 2>, attr, scan_lds_bytes(2, false));
     const int lds8 = scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES;
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, false>, attr, lds8);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, true>, attr, lds8);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 0>, attr, lds8);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 1>, attr, lds8);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 2>, attr, lds8);
   });
 }
 
@@ -1956,31 +2016,48 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   } else {
     sv.v = (const bf16_t*)v; sv.ld = (long long)H * GV; sv.col0 = 0; sv.w = nullptr; sv.st_in = nullptr; sv.st_out = nullptr;
   }
-  bool single = pf != nullptr && sync != nullptr && ncw == 2 && NT <= SYNC_HEAD_WORDS && B * H <= SYNC_MAX_HEADS &&
-                NT * B * H + (16 / 2) * B * H <= SINGLE_MAX_BLOCKS;
+  const int BH = B * H;
+  const bool can_sync = pf != nullptr && sync != nullptr && ncw == 2 && BH <= SYNC_MAX_HEADS;
+  bool single = can_sync && NT * BH + (16 / 2) * BH <= SINGLE_MAX_BLOCKS;
+  // long calls: one launch per segment with the scan workgroups first -- needs twice as many CUs as scan workgroups
+  bool overlap = can_sync && !single && 2 * 8 * BH <= device_cu_count();
 #ifdef IVL_TRACE
   single = single && g_gdn_single != 0;
+  overlap = overlap && g_gdn_single != 0 && g_gdn_single != 3;
 #endif
+  ScanSync sy;
+  if (can_sync) {
+    sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.BH = BH; sy.nprod = 1u;
+  }
+  const int lds1 = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
   if (single) {
-    bool split = 2 * NT * B * H + 8 * B * H <= SINGLE_MAX_BLOCKS;
+    bool split = 2 * NT * BH + 8 * BH <= SINGLE_MAX_BLOCKS;
 #ifdef IVL_TRACE
     split = split && g_gdn_single != 2;
 #endif
-    ScanSync sy;
-    sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.BH = B * H;
     sy.nprod = split ? 2u : 1u;
-    const int lds = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
     if (split)
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, true>), dim3(2 * NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb,
-                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 1>), dim3(2 * NT * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, scale, sy);
     else
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, false>), dim3(NT * B * H + 8 * B * H), dim3(SINGLE_THREADS), lds, st, *pf, wsb,
-                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, B * H, NT, scale, sy);
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 0>), dim3(NT * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, scale, sy);
     return check_launch("ivl_gdn_chunk_fused_fwd(single launch)");
   }
   for (int c0 = 0; c0 < NT; c0 += segc) {
     const int nseg = (NT - c0) < segc ? (NT - c0) : segc;
     const bool first = c0 == 0, last = c0 + nseg >= NT;
+    if (overlap) {
+      const void* hin = first ? h0 : (const void*)carry;
+      const int hin_dt = first ? h0_dtype : IVL_F32;
+      void* hout = last ? ht : (void*)carry;
+      const int hout_dt = last ? ht_dtype : IVL_F32;
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nseg * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
+                         (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, scale, sy);
+      int rc = check_launch("ivl_gdn_chunk_fused_fwd(overlapped launch)");
+      if (rc != IVL_OK) return rc;
+      continue;
+    }
     if (pf != nullptr)
       hipLaunchKernelGGL((gdn_chunk_prepare_kernel<F8, true>), dim3(nseg, B * H), dim3(512), P_BYTES, st, (const bf16_t*)nullptr,
                          (const bf16_t*)nullptr, (const float*)nullptr, (const bf16_t*)nullptr, *pf, wsb, T, H, c0 * GC, nseg,
