@@ -198,6 +198,7 @@ _GDN_SINGLE_LAUNCH = True      # tests switch it off to compare the single-launc
 def _gdn_sync_area(device: torch.device) -> torch.Tensor:
     """The flag words of ivl_gdn_chunk_fused_fwd's single-launch form (include/ivl_hip.h): zeroed here once, then owned by
     the library (every launch leaves it all-zero).  One per device: the package issues its calls on one stream."""
+    device = torch.device(device)
     dev = device.index if device.index is not None else torch.cuda.current_device()
     area = _GDN_SYNC.get(dev)
     if area is None:

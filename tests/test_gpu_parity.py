@@ -1353,6 +1353,33 @@ def test_linear_small_m_error_behaviour():
     assert lib.ivl_linear_small_m_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 5, 16, 64, None) == _lib.IVL_ERR_UNSUPPORTED
     assert lib.ivl_linear_small_m_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 1, 16, 60, None) == _lib.IVL_ERR_INVALID_ARG
     assert lib.ivl_linear_small_m_fwd(None, w.data_ptr(), None, y.data_ptr(), 1, 16, 64, None) == _lib.IVL_ERR_INVALID_ARG
+    # norm + projection: the norm weight is mandatory, a residual needs somewhere to put the new residual stream, K <= 4096
+    nw = torch.ones(64, dtype=torch.bfloat16, device=DEV)
+    xp, wp, yp, nwp = x.data_ptr(), w.data_ptr(), y.data_ptr(), nw.data_ptr()
+    assert lib.ivl_norm_linear_small_m_fwd(xp, None, None, 1e-6, None, wp, None, yp, 1, 16, 64, 0, None) == _lib.IVL_ERR_INVALID_ARG
+    assert lib.ivl_norm_linear_small_m_fwd(xp, xp, nwp, 1e-6, None, wp, None, yp, 1, 16, 64, 0, None) == _lib.IVL_ERR_INVALID_ARG
+    assert lib.ivl_norm_linear_small_m_fwd(xp, None, nwp, 1e-6, None, wp, None, yp, 1, 16, 8192, 0, None) == _lib.IVL_ERR_UNSUPPORTED
+    assert lib.ivl_norm_linear_small_m_fwd(xp, None, nwp, 1e-6, None, wp, None, yp, 5, 16, 64, 0, None) == _lib.IVL_ERR_UNSUPPORTED
+
+
+def test_gdn_chunk_fused_rejects_a_misaligned_sync_area():
+    """ivl_gdn_chunk_fused_fwd: the optional sync area must be 16-byte aligned (IVL_ERR_INVALID_ARG -> ValueError)."""
+    from infinitevl_amd import ops
+    H, K, V, T = 16, 128, 256, 64
+    Dq, Dk, Dv = H * K, H * K, H * V
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+    proj = torch.zeros(1, T, cols[4] + H, dtype=torch.bfloat16, device=DEV)
+    cw = [torch.zeros(D_, 1, 4, dtype=torch.bfloat16, device=DEV) for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    good = ops._gdn_sync_area(torch.device(DEV))
+    bad = torch.zeros(good.numel() + 16, dtype=torch.uint8, device=DEV)[4:]
+    key = [k for k, v in ops._GDN_SYNC.items() if v is good][0]
+    ops._GDN_SYNC[key] = bad
+    try:
+        with pytest.raises(ValueError):
+            ops.gdn_chunk_fused(proj, cols, cw, [None] * 3, [None] * 3, A32, dt32, H, K, V)
+    finally:
+        ops._GDN_SYNC[key] = good
 
 
 def test_decode_step_uses_weight_stream_and_matches_gemm_path():
@@ -1584,7 +1611,7 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma):
             ops._GDN_SINGLE_LAUNCH = True
         return o, ht, so
 
-    area = ops._gdn_sync_area(DEV)
+    area = ops._gdn_sync_area(torch.device(DEV))
     # the two-launch reference of every input set first, then the single-launch calls back to back: a record line left in
     # some L2 by an earlier launch would belong to different inputs
     sets, refs = [], []
