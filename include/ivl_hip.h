@@ -304,7 +304,7 @@ IVL_API int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, 
  * the decoder layer's input_layernorm -> q|k|v / GDN in-projection, post_attention_layernorm -> gate|up, and the final
  * norm -> lm_head (std:1350-1429, 1573, 2091-2092) at q_len == 1: 73 one-row norm launches per token disappear.
  *   h = bf16(x + residual) (residual NULL: h = x; else written to h_out [M,K]);  xn = bf16(norm_weight * bf16(h * rstd(h)));
- *   y = linear(xn).  x, residual, h_out bf16 [M,K]; norm_weight bf16 [K]; K <= 4096; the rest as the two entry points above. */
+ *   y = linear(xn).  x, residual, h_out bf16 [M,K]; norm_weight bf16 [K]; 512 <= K <= 4096; the rest as the two entry points above. */
 IVL_API int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, const void* norm_weight, float eps, void* h_out,
                                 const void* w, const void* bias, void* y, int M, int N, int K, int glu, void* stream);
 

@@ -225,8 +225,9 @@ extern "C" int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, 
                                            const void* w, const void* bias, void* y, int M, int N, int K, int glu, void* stream) {
   IVL_REQUIRE(norm_weight != nullptr, IVL_ERR_INVALID_ARG, "ivl_norm_linear_small_m_fwd: NULL norm weight");
   IVL_REQUIRE(residual == nullptr || h_out != nullptr, IVL_ERR_INVALID_ARG, "ivl_norm_linear_small_m_fwd: residual needs h_out");
-  IVL_REQUIRE(K <= LSM_NORM_KMAX, IVL_ERR_UNSUPPORTED, "ivl_norm_linear_small_m_fwd: K=%d (the normalised rows are staged in LDS: K <= %d)", K,
-              LSM_NORM_KMAX);
+  // (K >= 512: every lane of a wave must enter the weight loop, whose first trip holds the workgroup barriers of the norm)
+  IVL_REQUIRE(K >= 512 && K <= LSM_NORM_KMAX, IVL_ERR_UNSUPPORTED,
+              "ivl_norm_linear_small_m_fwd: K=%d (the normalised rows are staged in LDS by the whole workgroup: 512 <= K <= %d)", K, LSM_NORM_KMAX);
   NormArgs na;
   na.residual = (const bf16_t*)residual; na.weight = (const bf16_t*)norm_weight; na.h_out = (bf16_t*)h_out; na.eps = eps;
   return lsm_dispatch<true>(x, w, bias, y, M, glu ? N : N, K, glu != 0, na, stream, "ivl_norm_linear_small_m_fwd");

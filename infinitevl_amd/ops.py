@@ -562,7 +562,7 @@ def _prenorm_linear(pn: "PreNorm", weight: torch.Tensor, bias: Optional[torch.Te
     K = weight.shape[-1]
     rows = pn.numel() // K if K else 0
     if not (pn.is_cuda and 1 <= rows <= 4 and pn.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
-            and weight.is_contiguous() and K % 8 == 0 and K <= 4096 and pn.shape[-1] == K and pn._y is None
+            and weight.is_contiguous() and K % 8 == 0 and 512 <= K <= 4096 and pn.shape[-1] == K and pn._y is None
             and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))):
         return None
     N = weight.shape[0] // 2 if glu else weight.shape[0]
