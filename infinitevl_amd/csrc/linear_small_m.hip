@@ -39,8 +39,10 @@ struct NormArgs {
 constexpr int LSM_NORM_KMAX = 4096;
 
 // N = number of OUTPUT columns (GLU: I; the weight then has 2N rows)
-template <int RPW, int M, bool GLU, bool NORM>
-__global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+// NIT: 16-byte pieces of a row per thread in the norm prologue (1: K <= 2048 -- the hidden size of the model; 2: K <= 4096);
+// the prologue's registers are live while the first weight batch is in flight, and 218 VGPRs meant 2 workgroups per CU
+template <int RPW, int M, bool GLU, bool NORM, int NIT = 2>
+__global__ __launch_bounds__(256, NORM ? 3 : 1) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
                                                             int N, int K, NormArgs na) {
   constexpr int NR = GLU ? 2 * RPW : RPW;          // weight rows per wave
@@ -66,10 +68,10 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __res
   // requested behind the weight pieces they would only arrive behind the whole weight stream of the wave -- then the weight
   // pieces; norm_rows (every wave: workgroup barriers inside) then runs while the weights are in flight.
   const int tid = threadIdx.x;
-  u32x4 xraw[NORM ? M : 1][2], rraw[NORM ? M : 1][2], wraw[2];
+  u32x4 xraw[NORM ? M : 1][NIT], rraw[NORM ? M : 1][NIT], wraw[NIT];
   if constexpr (NORM) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int v = min(tid + it * 256, nchunk - 1);
       wraw[it] = *(const u32x4*)(na.weight + v * 8);
 #pragma unroll
@@ -80,12 +82,12 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __res
     }
   }
   auto norm_rows = [&]() {
-    float hv[M][2][8];
+    float hv[M][NIT][8];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       float ss = 0.f;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int v = tid + it * 256;
         if (v < nchunk) {
           unpack8(xraw[m][it], hv[m][it]);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __res
       const float tot = s_part[m][0] + s_part[m][1] + s_part[m][2] + s_part[m][3];
       const float rstd = rsqrtf(tot / (float)K + na.eps);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int v = tid + it * 256;
         if (v < nchunk) {
           float wv8[8], o8[8];
@@ -178,6 +180,15 @@ static void launch_lsm(const bf16_t* x, const bf16_t* w, const bf16_t* bias, bf1
                        hipStream_t st) {
   const int rows_per_wg = 4 * RPW;
   dim3 grid((N + rows_per_wg - 1) / rows_per_wg);
+  if (NORM && K <= 2048) {
+    switch (M) {
+      case 1: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 1, GLU, NORM, 1>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+      case 2: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 2, GLU, NORM, 1>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+      case 3: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 3, GLU, NORM, 1>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+      default: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 4, GLU, NORM, 1>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
+    }
+    return;
+  }
   switch (M) {
     case 1: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 1, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;
     case 2: hipLaunchKernelGGL((linear_small_m_kernel<RPW, 2, GLU, NORM>), grid, dim3(256), 0, st, x, w, bias, y, N, K, na); break;

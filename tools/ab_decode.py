@@ -1,6 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-from infinitevl_amd import ops
+from infinitevl_amd import ops, _lib
+if os.environ.get("IVL_LIB"):
+    _lib.load(os.environ["IVL_LIB"])
 ops._PRENORM = os.environ["IVL_PRENORM"] == "1"
 from infinitevl_amd.harness import GraphedDecode, InfiniteVLTextConfig, InfiniteVLTextStack
 dev = torch.device("cuda", 0)
