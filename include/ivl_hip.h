@@ -14,6 +14,8 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
  *     the library never allocates, frees, synchronises or branches on device data on the
  *     host, so every call is hipGraph-capturable (SURVEY.md section 8b "Threading / streams").
+ *     (One exception: the first GDN chunk call on a device pins 64 bytes of host memory for the
+ *     status word of ivl_gdn_sync_status; ivl_gdn_sync_status(sync != NULL) is the one blocking call.)
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - layouts are the reference's time-major ones: q,k [B,T,H,K], v,o [B,T,H,V],
  *     g,beta [B,T,H], recurrent state [B,H,K,V]; bf16 activations, fp32 g.
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 7
+#define IVL_ABI_VERSION 8
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -46,6 +48,7 @@ extern "C" {
 #define IVL_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels are built for             */
 #define IVL_ERR_WORKSPACE (-3)     /* workspace too small (see the *_workspace_bytes helpers)  */
 #define IVL_ERR_LAUNCH (-4)        /* hipLaunch / hipGetLastError failure                      */
+#define IVL_ERR_SYNC (-5)          /* a wait inside a single-launch GDN call ran out (ivl_gdn_sync_status / _reset) */
 
 IVL_API int ivl_abi_version(void);
 IVL_API const char* ivl_last_error(void);
@@ -96,11 +99,20 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  * [B, D, 4] bf16 (in: NULL = zero history; out: NULL = not wanted; out may alias in).  The rest as ivl_gdn_chunk_fwd
  * (q/k l2norm always on, as the reference calls it).
  * `sync` (optional, NULL = always two launches): IVL_GDN_SYNC_BYTES of device memory, 16-byte aligned, that the CALLER
- *   zeroed once (hipMemset) before its first use and that nothing but this entry point has written since; one area per
- *   stream of concurrent calls.  With it, calls whose pre-pass and scan workgroups all fit the chip at once (B*H*(T/64 + 8)
- *   <= 256 and B*H <= 32: the 256-token streaming step) run as ONE launch: the scan workgroups start beside the pre-pass
- *   workgroups and wait on flags in this area, which the launch itself clears again (all-zero between launches, so the
- *   call is replayable from a hipGraph).  Results are bit-identical to the two-launch form.
+ *   zeroed (hipMemset or ivl_gdn_sync_reset) before its first use and that nothing but this library has written since; ONE
+ *   AREA PER STREAM of concurrent calls.  With it the call runs as ONE launch per 4096-token segment whenever the grid can
+ *   be resident at once (occupancy query x CU count; ivl_gdn_resident_blocks overrides it, 0 = always two
+ *   launches) and B*H <= 32:
+ *     - B*H*(T/64 + 8) workgroups fit (the 256-token streaming step): pre-pass and scan workgroups side by side, the scan
+ *       waiting on flags in this area; with room for twice the pre-pass workgroups the pre-pass is split in a k and a q side;
+ *     - longer calls, when the device holds 2 * 8*B*H workgroups: persistent pre-pass workgroups in front of the scan
+ *       workgroups, the scan consuming the records chunk by chunk as they are published.
+ *   The launch clears its flags again (all-zero between launches: replayable from a hipGraph).  Results are bit-identical to
+ *   the two-launch form.  Contract of the in-launch waits (csrc/gdn_chunk.hip, scan_wait_records): a workgroup only waits for
+ *   workgroups with lower block ids; every wait is bounded; a wait that runs out raises a sticky error word in the area and in
+ *   a host-visible status word, and the waiting workgroup stores NO output / state computed from records it has not seen.
+ *   After that this entry point returns IVL_ERR_SYNC for every call with a sync area on that device (and launches nothing)
+ *   until ivl_gdn_sync_reset; workgroups of launches already queued (a hipGraph) stop at once when they find the area failed.
  * ------------------------------------------------------------------------------------------- */
 #define IVL_GDN_SYNC_BYTES 16384
 IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
@@ -109,6 +121,17 @@ IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int
                             const float* dt_bias, void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype, int B,
                             int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
                             size_t workspace_bytes, void* sync, void* stream);
+/* Status of the single-launch forms on the CURRENT device: IVL_OK or IVL_ERR_SYNC (ivl_last_error(): which wait, head, chunk).
+ * sync == NULL: what the kernels have reported so far through the host-visible status word -- no stream work, callable at any
+ *   time, also during capture (a failure shows up once the failing kernel has run: check after a synchronisation point).
+ * sync != NULL: additionally copies the area's own error word back behind `stream` and waits for it (blocking; not capturable).
+ * ivl_gdn_sync_reset zeroes the area behind `stream` and clears the device's status word (also the way to initialise an area). */
+IVL_API int ivl_gdn_sync_status(const void* sync, void* stream);
+IVL_API int ivl_gdn_sync_reset(void* sync, void* stream);
+/* The number of single-launch workgroups the library takes to be resident at once on the current device (occupancy query x CU
+ * count: 256 on a whole MI355X).  override_blocks >= 0 replaces it process-wide -- 0 = always the two-launch form, a small
+ * number = a partitioned / shared device; < 0 restores the query.  Returns the number in force. */
+IVL_API int ivl_gdn_resident_blocks(int override_blocks);
 
 /* ---------------------------------------------------------------------------------------------
  * Gate math: beta = sigmoid(b) (bf16), g = -exp(A_log) * softplus(a + dt_bias) (fp32).

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 IVL_BF16, IVL_F32, IVL_FP8_E4M3 = 0, 2, 3
 IVL_OK = 0
 IVL_GDN_SYNC_BYTES = 16384
-IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH = -1, -2, -3, -4
+IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH, IVL_ERR_SYNC = -1, -2, -3, -4, -5
 
 EXPORTED_SYMBOLS = (
     "ivl_abi_version", "ivl_last_error",
@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "ivl_add_rmsnorm_fwd", "ivl_silu_mul_fwd", "ivl_linear_small_m_fwd",
     "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd", "ivl_rope_tables_fwd",
     "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd", "ivl_norm_linear_small_m_fwd",
+    "ivl_gdn_sync_status", "ivl_gdn_sync_reset", "ivl_gdn_resident_blocks",
 )
 
 
@@ -82,6 +83,13 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_chunk_fused_fwd.restype = i
     lib.ivl_gdn_chunk_fused_fwd.argtypes = ([vp, c_int64, i, i, i, i, i] + [vp] * 9 + [vp, vp, vp, vp, i, vp, i] +
                                             [i, i, i, i, i, i, f, i, vp, sz, vp, vp])
+    if path is None or hasattr(lib, "ivl_gdn_sync_status"):     # (a developer A/B against an older build lacks the v8 entries)
+        lib.ivl_gdn_sync_status.restype = i
+        lib.ivl_gdn_sync_status.argtypes = [vp, vp]
+        lib.ivl_gdn_sync_reset.restype = i
+        lib.ivl_gdn_sync_reset.argtypes = [vp, vp]
+        lib.ivl_gdn_resident_blocks.restype = i
+        lib.ivl_gdn_resident_blocks.argtypes = [i]
     lib.ivl_rope_tables_fwd.restype = i
     lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, vp]
     lib.ivl_vision_attn_workspace_bytes.restype = sz
@@ -125,6 +133,10 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_norm_linear_small_m_fwd.restype = i
     lib.ivl_norm_linear_small_m_fwd.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, i, i, i, i, vp]
     _lib = lib
+    # the one environment switch, on the Python side: IVL_GDN_RESIDENT_BLOCKS=0 forces the two-launch form of the fused GDN call
+    env = os.environ.get("IVL_GDN_RESIDENT_BLOCKS", "")
+    if env.strip():
+        lib.ivl_gdn_resident_blocks(int(env))
     return lib
 
 

@@ -132,6 +132,31 @@ __device__ __forceinline__ void put_piece(unsigned char* base, int idx, float a0
   else rec_st<DEV>(base + idx * 16, pack8(a0, a1, a2, a3, a4, a5, a6, a7));
 }
 
+// ---- single-launch forms: the sync area (protocol: see scan_wait_records below) -----------------------------------
+constexpr int SYNC_HEAD_WORDS = 64;       // flag words per head: one per chunk of a workspace segment (G_SEG_CHUNKS)
+enum { SYNC_E_START = 1, SYNC_E_GATE = 2, SYNC_E_KREAD = 3 };   // which wait ran out (error word, low byte)
+struct ScanSync {
+  unsigned int* flags = nullptr;            // flags[64 bh + c]: pre-pass workgroups of (bh, chunk c) that have published
+  unsigned int* headdone = nullptr;
+  unsigned int* kread = nullptr;            // kread[bh]: the q side of chunk 0 has read the old conv state of k (split pre-pass)
+  unsigned int* err = nullptr;              // err[0]: sticky error code (0 = healthy); err[1]: (bh << 16) | chunk of the first failure
+  unsigned int* host_err = nullptr;         // the same two words in pinned host memory (NULL: not available)
+  int BH = 0;
+  unsigned int nprod = 1;                   // pre-pass workgroups per chunk (2: split into a k side and a q side)
+};
+// one lane: record the first failure (device word for the workgroups of this and of later launches, host word for the C ABI)
+__device__ __forceinline__ void sync_fail(const ScanSync& sy, unsigned int code, int bh, int c) {
+  if (atomicCAS(sy.err, 0u, code) == 0u) {
+    const unsigned int where = ((unsigned int)bh << 16) | (unsigned int)(c & 0xffff);
+    __hip_atomic_store(sy.err + 1, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sy.host_err != nullptr) {
+      __hip_atomic_store(sy.host_err + 1, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(sy.host_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+constexpr int SYNC_SPIN_BOUND = 1 << 22;    // polls of ~0.2 us each (measured: 2^18 of them ~50 ms): ~1 s before a wait is declared failed
+
 // ==================================================================================================
 // (1) chunk-parallel pre-pass
 // ==================================================================================================
@@ -248,12 +273,12 @@ __device__ __forceinline__ void conv4_silu(const u32x4* xr, const u32x4* w, u32x
 // workgroup are launched one after the other -- and arrived at B1 later than wave 1 does with both jobs.)
 // The conv state of k is read by BOTH workgroups of chunk 0 and written (possibly in place) by the k side: the q side raises
 // `kread` once its loads of the old state have returned, the k side writes the new state at its very end, behind that word.
-template <bool F8, bool FUSED, bool DEV, int ROLE>
+template <bool F8, bool FUSED, bool DEV, int ROLE, bool LOOPED = false>
 __device__ __forceinline__ void gdn_chunk_prepare_body(
     unsigned char* smem, const int ci, const int bh,
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, const PrepFused& pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm,
-    unsigned int* done, unsigned int* kread) {
+    unsigned int* done, unsigned int* kread, const ScanSync* sy) {
   static_assert(ROLE == 0 || FUSED, "the split pre-pass exists for the fused front end only");
   constexpr bool KONLY = ROLE == 1, DO_K = ROLE != 2, DO_Q = ROLE != 1;
   using R = Rec<F8>;
@@ -270,7 +295,11 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
 #ifdef IVL_TRACE
   const unsigned long long rt_p0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the thread index passes through an empty asm statement: inside the persistent loop of the long-call form nothing derived
+  // from it is hoisted out of the body and kept alive across it -- the body stays at its straight-line register count)
+  int tid_opaque = threadIdx.x;
+  if constexpr (LOOPED) asm volatile("" : "+v"(tid_opaque));
+  const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int l31 = lane & 31, hi = lane >> 5;
   const int l15 = lane & 15, g4 = lane >> 4;
@@ -476,8 +505,11 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
           for (int j = 0; j < 4; ++j) keep_tl[j] = tl[j];
 #pragma unroll
           for (int j = 0; j < 3; ++j) keep_h[j] = xr[j];
-        } else if (pf.st_out[1] != nullptr && oct == 0) {              // ROLE 2, k waves: the old state has been read (history
-          __hip_atomic_store(kread, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed it: the loads have returned)
+        } else if (pf.st_out[1] != nullptr) {                          // ROLE 2, k waves: the old state has been read: history
+          // consumed it.  The explicit wait keeps the store behind the RETURN of the loads whatever the compiler schedules (a
+          // relaxed atomic is not ordered against ordinary loads); it costs nothing, st4 was the wave's youngest load
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (oct == 0) __hip_atomic_store(kread, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       if (second_run) {
@@ -807,9 +839,15 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
     // state too once `kread` is up (bounded wait, as scan_wait_records) -- cleared again for the next launch.  Behind the
     // publish: the scan does not read the conv state, and the device-scope load of the word is a full memory round trip
     if (t0 == 0 && tid < 16 && pf.st_out[1] != nullptr) {
-      for (int spin = 0; spin < (1 << 20); ++spin) {
-        if (__hip_atomic_load(kread, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      bool read = false;
+      for (int spin = 0; spin < SYNC_SPIN_BOUND; ++spin) {
+        if (__hip_atomic_load(kread, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { read = true; break; }
+        if ((spin & 31) == 31 && __hip_atomic_load(sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         __builtin_amdgcn_s_sleep(2);
+      }
+      if (!read) {                                                     // (uniform over the 16 threads) the old state may still be
+        if (tid == 0) sync_fail(*sy, SYNC_E_KREAD, bh, 0);             // unread: it is NOT overwritten, the failure is reported
+        return;
       }
       if (tid == 0) __hip_atomic_store(kread, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (put_state is defined in the front-end scope: the same transposition, inlined here)
@@ -845,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void gdn_chunk_prepare_kernel(
     const bf16_t* __restrict__ beta, PrepFused pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   gdn_chunk_prepare_body<F8, FUSED, false, 0>(smem, (int)blockIdx.x, (int)blockIdx.y, q, k, g, beta, pf, ws, T, H, t_seg0, nt_seg, l2norm, nullptr,
-                                              nullptr);
+                                              nullptr, nullptr);
 }
 
 // ==================================================================================================
@@ -880,33 +918,37 @@ static_assert(scan_lds_bytes(4, false) <= 160 * 1024, "scan LDS budget");
 // LDS-DMA, NP consecutive 1 KB pieces: global [gsrc + 1024 p + 16 lane] -> LDS [lds_dst + 1024 p + 16 lane], p = 0..NP-1
 // (the instruction offset is added to both addresses).  gsrc and lds_dst are wave-uniform (SGPRs); hipcc does not count
 // these operations: completion is awaited with explicit counted s_waitcnt vmcnt and published by the following barrier.
-template <int NP>
+// DEV (single-launch forms): the source is a record that ANOTHER workgroup of the same launch has written (device-scope
+// `sc1` stores, flag raised behind their acknowledgement).  The loads carry `sc1` as well: they are served by the L2, never by
+// a line this CU's vector L1 may hold -- the consumer half of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility:
+// "sc1 loads may replace the acquire only when the producer stored sc1"; cdna_hip_programming.md Guideline 16, R1).
+#define IVL_DMA_BODY(NP_, SC_)                                                                                   \
+  if constexpr (NP_ == 4)                                                                                        \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                                          \
+                 "global_load_lds_dwordx4 %1, %3" SC_ "\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024" SC_ "\n\t"  \
+                 "global_load_lds_dwordx4 %1, %3 offset:2048" SC_ "\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072" SC_ "\n\t" \
+                 "s_mov_b32 m0, %0"                                                                              \
+                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");                              \
+  else if constexpr (NP_ == 3)                                                                                   \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                                          \
+                 "global_load_lds_dwordx4 %1, %3" SC_ "\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024" SC_ "\n\t"  \
+                 "global_load_lds_dwordx4 %1, %3 offset:2048" SC_ "\n\t"                                          \
+                 "s_mov_b32 m0, %0"                                                                              \
+                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");                              \
+  else if constexpr (NP_ == 2)                                                                                   \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                                          \
+                 "global_load_lds_dwordx4 %1, %3" SC_ "\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024" SC_ "\n\t"  \
+                 "s_mov_b32 m0, %0"                                                                              \
+                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");                              \
+  else                                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" SC_ "\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory")
+template <int NP, bool DEV = false>
 __device__ __forceinline__ void dma_pieces(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
   static_assert(NP >= 1 && NP <= 4, "pieces per issue");
   unsigned int keep;
-  if constexpr (NP == 4)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %3 offset:2048\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
-  else if constexpr (NP == 3)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
-  else if constexpr (NP == 2)
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane16), "s"(lds_dst), "s"(gsrc) : "memory");
+  if constexpr (DEV) { IVL_DMA_BODY(NP, " sc1"); }
+  else { IVL_DMA_BODY(NP, ""); }
 }
 // workgroup barrier that waits for this wave's LDS traffic only (no vector-memory drain)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -928,23 +970,23 @@ __host__ __device__ constexpr int loader_pieces(int L, int n) {               //
 __host__ __device__ constexpr int loader_n1(int L, bool f8) { return loader_pieces(L, h1_pieces(f8)) + (L == 0 ? 1 : 0); }
 __host__ __device__ constexpr int loader_n2(int L, bool f8) { return loader_pieces(L, h2_pieces(f8)); }
 
-template <int L, int NPIECES, int U = 0>
+template <int L, int NPIECES, bool DEV, int U = 0>
 __device__ __forceinline__ void load_region(const unsigned char* gsrc, unsigned int lds_dst, unsigned int lane16) {
   if constexpr (4 * U < NPIECES) {
-    if constexpr (U % SCAN_NL == L) dma_pieces<unit_size(U, NPIECES)>(gsrc + U * 4096, lds_dst + (unsigned int)(U * 4096), lane16);
-    load_region<L, NPIECES, U + 1>(gsrc, lds_dst, lane16);
+    if constexpr (U % SCAN_NL == L) dma_pieces<unit_size(U, NPIECES), DEV>(gsrc + U * 4096, lds_dst + (unsigned int)(U * 4096), lane16);
+    load_region<L, NPIECES, DEV, U + 1>(gsrc, lds_dst, lane16);
   }
 }
-template <int L, bool F8>
+template <int L, bool F8, bool DEV>
 __device__ __forceinline__ void load_h1(const unsigned char* rec, unsigned int img, unsigned int lane16) {
   using R = Rec<F8>;
-  load_region<L, h1_pieces(F8)>(rec + R::WN, img + (unsigned int)R::WN, lane16);
-  if (L == 0) dma_pieces<1>(rec + R::EG, img + (unsigned int)R::EG, lane16);
+  load_region<L, h1_pieces(F8), DEV>(rec + R::WN, img + (unsigned int)R::WN, lane16);
+  if (L == 0) dma_pieces<1, DEV>(rec + R::EG, img + (unsigned int)R::EG, lane16);
 }
-template <int L, bool F8>
+template <int L, bool F8, bool DEV>
 __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int img, unsigned int lane16) {
   using R = Rec<F8>;
-  load_region<L, h2_pieces(F8)>(rec + R::KDT, img + (unsigned int)R::KDT, lane16);
+  load_region<L, h2_pieces(F8), DEV>(rec + R::KDT, img + (unsigned int)R::KDT, lane16);
 }
 
 // Barrier protocol (every wave of the workgroup executes the same sequence PA, P0, P, T(0), M(0), T(1), M(1), ..., F):
@@ -1022,17 +1064,17 @@ __device__ __forceinline__ void load_vt(const ScanTouch& tc, int c, int nt_seg, 
 // loader 3) into buffer c & 1
 template <int L>
 __host__ __device__ constexpr int tu_instrs() { return L == 1 ? 3 : (L == 2 ? 2 : (L == 3 ? 1 : 0)); }
-template <int L, bool F8>
+template <int L, bool F8, bool DEV>
 __device__ __forceinline__ void load_tu(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, unsigned int lane16) {
   if constexpr (tu_instrs<L>() > 0) {
     c = c < nt_seg ? c : nt_seg - 1;
     constexpr int P0_ = L == 1 ? 0 : (L == 2 ? 3 : 5);
     const unsigned char* src = ws_bh + (size_t)c * Rec<F8>::STRIDE + Rec<F8>::TU + P0_ * 1024;
     const unsigned int dst = tc.tub + (unsigned int)((c & 1) * Img<F8>::TU_BYTES + P0_ * 1024);
-    dma_pieces<tu_instrs<L>()>(src, dst, lane16);
+    dma_pieces<tu_instrs<L>(), DEV>(src, dst, lane16);
   }
 }
-template <int L, bool F8>
+template <int L, bool F8, bool DEV>
 __device__ __forceinline__ void load_beta(const ScanTouch& tc, const unsigned char* ws_bh, int c, int nt_seg, int lane) {
   if constexpr (L != 3) return;
   c = c < nt_seg ? c : nt_seg - 1;
@@ -1040,8 +1082,12 @@ __device__ __forceinline__ void load_beta(const ScanTouch& tc, const unsigned ch
   const unsigned int dst = tc.betab + (unsigned int)((c & 1) * Img<F8>::BETA_BYTES);
   const unsigned int off = 4u * (unsigned int)lane;
   unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(dst), "s"(src) : "memory");
+  if constexpr (DEV)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(src) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(src) : "memory");
 }
 
 template <int N>
@@ -1050,45 +1096,73 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Single-launch form (small grids: every workgroup of the pre-pass AND of the scan is resident at once): the scan workgroups
-// start together with the pre-pass workgroups of the same launch, fetch what does not depend on the records (value tiles, the
-// initial state), and their loader waves wait here for the flags of the head's records.  flags[16 bh + c] is raised by the
-// pre-pass workgroup of (chunk c, head bh) and cleared again by the LAST of the head's scan workgroups to have passed the wait
-// (counted in headdone[bh], which it also clears): the area is all-zero between launches -- the caller zeroes it once.
-constexpr int SYNC_HEAD_WORDS = 64;       // flag words per head: one per chunk of a workspace segment (G_SEG_CHUNKS)
-struct ScanSync {
-  unsigned int* flags = nullptr;            // flags[16 bh + c]: pre-pass workgroups of (bh, chunk c) that have published
-  unsigned int* headdone = nullptr;
-  unsigned int* kread = nullptr;            // kread[bh]: the q side of chunk 0 has read the old conv state of k (split pre-pass)
-  int BH = 0;
-  unsigned int nprod = 1;                   // pre-pass workgroups per chunk (2: split into a k side and a q side)
-};
+// Single-launch forms: the scan workgroups start together with the pre-pass workgroups of the same launch, fetch what does
+// not depend on the records (value tiles, the initial state), and their loader waves wait here for the flags of the head's
+// records.  flags[64 bh + c] is raised by the pre-pass workgroup(s) of (chunk c, head bh) and cleared again by the LAST of the
+// head's scan workgroups to have passed its waits (counted in headdone[bh], which it also clears): the area is all-zero between
+// launches -- the caller zeroes it once.
+//
+// What the forms rest on, and what they do NOT rest on:
+//  * LIVENESS: a workgroup only ever waits for workgroups with LOWER block ids (pre-pass ids < scan ids; the q side of chunk 0,
+//    whose `kread` the k side awaits, has the lowest ids of all; the long-call pre-pass is a set of PERSISTENT workgroups in
+//    front of the scan workgroups).  The hardware dispatches a grid in id order, so every awaited workgroup has been
+//    dispatched -- and, never waiting itself for anything younger, finishes -- whatever share of the chip the launch gets (a
+//    second stream, a second process, a partitioned device).  HIP does not promise the order (MI355X_MICROARCH.md, Workgroup
+//    dispatch): it is relied on for progress only, never for results.
+//  * SAFETY does not rest on it: every wait is bounded, and a wait that runs out (or that finds the area already failed) raises
+//    a STICKY error word in the sync area and in a host-visible status word, and the workgroup stops: it stores no output
+//    and no state computed from records it has not seen.  ivl_gdn_chunk_fused_fwd refuses to launch on a failed area
+//    (IVL_ERR_SYNC), ivl_gdn_sync_status reports it, ivl_gdn_sync_reset re-arms the area.
+//  * VISIBILITY (cdna_hip_programming.md Guideline 16, R1): records are stored write-through (`sc1`), every storing wave drains
+//    (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane raises the flag (agent-scope atomic); the consumer polls relaxed with
+//    agent-scope loads and reads the records with `sc1` loads (LDS-DMA), which the vector L1 cannot serve.
 // the loader waves' wait at the start: every record of the call (small grids: the pre-pass workgroups all finish together), or,
 // for long calls (`progressive`), the records of chunks 0..2 (what the loaders request in front of the first chunk step) -- the
-// later chunks are then awaited by V wave 0, three chunks ahead of the state waves (scan_vwave)
+// later chunks are then awaited by V wave 0, three chunks ahead of the state waves (scan_vwave).
+// Lane c watches chunk c, lane 63 the area's error word.  false: the wait ran out or the area had failed before (the caller
+// then loads nothing from the records and tells its workgroup through the abort words in LDS).
 template <bool PROGRESSIVE>
-__device__ __forceinline__ void scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
-  const int nw = PROGRESSIVE ? (nt_seg < 3 ? nt_seg : 3) : nt_seg;         // (all at once: nt_seg <= 64 lanes)
-  const unsigned int* p = sy.flags + bh * SYNC_HEAD_WORDS + (lane < nw ? lane : 0);        // lane c watches chunk c
-  // bounded (~0.1 s): the pre-pass workgroups have lower block ids and are dispatched first, so the wait ends within the
-  // pre-pass's few microseconds; the bound only keeps a broken contract (a sync area shared by concurrent calls) from
-  // hanging the device
-  for (int spin = 0; spin < (1 << 20); ++spin) {
+__device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
+  const int nw = PROGRESSIVE ? (nt_seg < 3 ? nt_seg : 3) : nt_seg;         // (all at once: the host keeps nt_seg <= 63)
+  const unsigned int* p = lane == 63 ? sy.err : sy.flags + bh * SYNC_HEAD_WORDS + (lane < nw ? lane : 0);
+  for (int spin = 0; spin < SYNC_SPIN_BOUND; ++spin) {
     const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_amdgcn_ballot_w64(v != sy.nprod) == 0ull) break;
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != (lane == 63 ? 0u : sy.nprod));
+    if (bad == 0ull) return true;
+    if (bad >> 63) return false;                                           // the area has failed before: no use waiting
     __builtin_amdgcn_s_sleep(4);
   }
+  if (lane == 0) sync_fail(sy, SYNC_E_START, bh, 0);
+  return false;
+}
+// Abort words of a scan workgroup (LDS, the first dwords of the otherwise unused `dummy` area of the 32-column workgroup):
+// word L = loader L's wait failed (written by every loader before PA, 0 or 1), word 4 = the gate wave's (V wave 0, long
+// calls: 0 before PA, 1 when a later chunk's wait runs out).  Read by every wave behind PA, by the output waves at every chunk
+// step and by the state waves in front of their state store: nothing computed from unseen records leaves the workgroup.
+template <bool F8> __device__ __forceinline__ unsigned int* scan_abort_words(unsigned char* smem) {
+  return (unsigned int*)(smem + Img<F8>::dummy(2));
+}
+template <bool F8, bool WITH_GATE> __device__ __forceinline__ bool scan_aborted(unsigned char* smem) {
+  const u32x4 a = *(const u32x4*)scan_abort_words<F8>(smem);
+  unsigned int any = a.x | a.y | a.z | a.w;
+  if constexpr (WITH_GATE) any |= scan_abort_words<F8>(smem)[4];
+  return __builtin_amdgcn_readfirstlane(any) != 0u;
 }
 
 // SYNC: 0 = records from an earlier launch; 1 = single launch, all records awaited at the start; 2 = long calls (progressive)
 template <int L, int NCW, bool F8, int SYNC>
-__device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned int lds0, unsigned int lane16, const ScanTouch& tc,
-                                            int lane, const ScanSync& sy, int bh, bool trace_wg) {
+__device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_seg, unsigned char* smem, unsigned int lds0, unsigned int lane16,
+                                            const ScanTouch& tc, int lane, const ScanSync& sy, int bh, bool trace_wg) {
   (void)trace_wg;
   constexpr int N1 = loader_n1(L, F8), N2 = loader_n2(L, F8);               // pieces per half image issued by this loader
   // NCW = 4: the V waves load their rows / Tu / beta themselves, loaders 2, 3 warm the L2 for them (one touch per chunk)
   // NCW = 2: the loaders fetch the value tile, beta (with H2: the "T batch") and Tu (with H1: the "M batch") for real
   constexpr bool VD = NCW == 2;
+#ifdef IVL_AB_NO_SC1
+  constexpr bool DEV = false;                                               // (developer A/B only)
+#else
+  constexpr bool DEV = SYNC != 0;                                           // the records come from workgroups of this launch: sc1 loads
+#endif
   constexpr int TW = VD ? 0 : (L == 2 || L == 3 ? L : 0);                   // what this loader touches (2: value rows, 3: Tu / beta)
   constexpr int NT = TW != 0 ? 1 : 0;                                       // touch instructions per chunk
   constexpr int NVB = VD ? vt_instrs<L>() + (L == 3 ? 1 : 0) : 0;           // value tile + beta instructions per chunk
@@ -1097,7 +1171,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   auto rec = [&](int ci) { return ws_bh + (size_t)ci * Rec<F8>::STRIDE; };
   auto img = [&](int ci) { return lds0 + (unsigned int)((ci & 1) * Img<F8>::BYTES); };
   auto vset = [&](int c) {                                                   // value tile, beta (and Tu at the start) of chunk c
-    if constexpr (VD) { load_vt<L, F8>(tc, c, nt_seg, lane); load_beta<L, F8>(tc, ws_bh, c, nt_seg, lane); }
+    if constexpr (VD) { load_vt<L, F8>(tc, c, nt_seg, lane); load_beta<L, F8, DEV>(tc, ws_bh, c, nt_seg, lane); }
   };
   // issue order at the start: chunk 0's value tile, beta, Tu (the V waves' conversion + product of chunk 0 stand between their
   // arrival and the first chunk step) | H1(0) | chunk 1's set | H2(0) | H1(1) | touches
@@ -1107,33 +1181,42 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     constexpr int NB = L == 3 ? 1 : 0;
     load_vt<L, F8>(tc, 0, nt_seg, lane);
     load_vt<L, F8>(tc, 1, nt_seg, lane);
-    scan_wait_records<SYNC == 2>(sy, bh, nt_seg, lane);
+    const bool seen = scan_wait_records<SYNC == 2>(sy, bh, nt_seg, lane);
+    if (lane == 0) scan_abort_words<F8>(smem)[L] = seen ? 0u : 1u;
+    if (!seen) {                                                 // (wave-uniform) nothing is read from the records: the workgroup stops behind PA
+      wait_vm<0>();
+      lds_barrier();                                             // PA
+      return;
+    }
 #ifdef IVL_TRACE
     if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[42] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    load_beta<L, F8>(tc, ws_bh, 0, nt_seg, lane);
-    load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
-    load_h1<L, F8>(rec(0), img(0), lane16);
-    load_beta<L, F8>(tc, ws_bh, 1, nt_seg, lane);
-    load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
-    load_h2<L, F8>(rec(0), img(0), lane16);
-    if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
+    load_beta<L, F8, DEV>(tc, ws_bh, 0, nt_seg, lane);
+    load_tu<L, F8, DEV>(tc, ws_bh, 0, nt_seg, lane16);
+    load_h1<L, F8, DEV>(rec(0), img(0), lane16);
+    load_beta<L, F8, DEV>(tc, ws_bh, 1, nt_seg, lane);
+    load_tu<L, F8, DEV>(tc, ws_bh, 1, nt_seg, lane16);
+    load_h2<L, F8, DEV>(rec(0), img(0), lane16);
+    if (nt_seg > 1) load_h1<L, F8, DEV>(rec(1), img(1), lane16);
     if (nt_seg > 1) wait_vm<N1 + NB + NTU + N2 + N1>();          // chunk 0's beta / Tu have landed (its value tile long before)
     else wait_vm<N1 + NB + NTU + N2>();
   } else {
     vset(0);
-    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 0, nt_seg, lane16);
-    load_h1<L, F8>(rec(0), img(0), lane16);
+    if constexpr (VD) load_tu<L, F8, DEV>(tc, ws_bh, 0, nt_seg, lane16);
+    load_h1<L, F8, DEV>(rec(0), img(0), lane16);
     vset(1);
-    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 1, nt_seg, lane16);
-    load_h2<L, F8>(rec(0), img(0), lane16);
-    if (nt_seg > 1) load_h1<L, F8>(rec(1), img(1), lane16);
+    if constexpr (VD) load_tu<L, F8, DEV>(tc, ws_bh, 1, nt_seg, lane16);
+    load_h2<L, F8, DEV>(rec(0), img(0), lane16);
+    if (nt_seg > 1) load_h1<L, F8, DEV>(rec(1), img(1), lane16);
     touch_chunk<TW, F8>(tc, ws_bh, 3, nt_seg, lane);
     touch_chunk<TW, F8>(tc, ws_bh, 4, nt_seg, lane);
     if (nt_seg > 1) wait_vm<N1 + NVB + NTU + N2 + N1 + 2 * NT>();   // chunk 0's value tile / beta / Tu have landed
     else wait_vm<N1 + NVB + NTU + N2 + 2 * NT>();
   }
   lds_barrier();                                               // PA
+  if constexpr (SYNC != 0) {
+    if (scan_aborted<F8, false>(smem)) { wait_vm<0>(); return; }   // another loader's wait failed
+  }
 #ifdef IVL_TRACE
   if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[43] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -1142,7 +1225,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   if (nt_seg > 1) wait_vm<N2 + N1 + 2 * NT + NVB>();           // H1(0) and chunk 1's set have landed
   else wait_vm<N2 + 2 * NT + NVB>();
   lds_barrier();                                               // P
-  if constexpr (VD) load_tu<L, F8>(tc, ws_bh, 2, nt_seg, lane16);   // Tu buffer 0 is free: u(0) has been formed
+  if constexpr (VD) load_tu<L, F8, DEV>(tc, ws_bh, 2, nt_seg, lane16);   // Tu buffer 0 is free: u(0) has been formed
   IVL_TVAR(lt_vmT); IVL_TVAR(lt_wT); IVL_TVAR(lt_iss2); IVL_TVAR(lt_vmM); IVL_TVAR(lt_wM); IVL_TVAR(lt_iss1);
   for (int ci = 0; ci < nt_seg; ++ci) {
     IVL_T(l0);
@@ -1154,15 +1237,15 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     IVL_T(l1);
     lds_barrier();                                             // T(ci)
     IVL_T(l2);
-    if (ci + 1 < nt_seg) load_h2<L, F8>(rec(ci + 1), img(ci + 1), lane16);
+    if (ci + 1 < nt_seg) load_h2<L, F8, DEV>(rec(ci + 1), img(ci + 1), lane16);
     vset(ci + 3);
     IVL_T(l3);
     if (ci + 1 < nt_seg) wait_vm<NTB + NTU + NT>();            // H1(ci+1) has landed: the rest of its M batch and the T batch behind it
     IVL_T(l4);
     lds_barrier();                                             // M(ci)
     IVL_T(l5);
-    if (ci + 2 < nt_seg) load_h1<L, F8>(rec(ci + 2), img(ci + 2), lane16);
-    if constexpr (VD) load_tu<L, F8>(tc, ws_bh, ci + 3, nt_seg, lane16);
+    if (ci + 2 < nt_seg) load_h1<L, F8, DEV>(rec(ci + 2), img(ci + 2), lane16);
+    if constexpr (VD) load_tu<L, F8, DEV>(tc, ws_bh, ci + 3, nt_seg, lane16);
     touch_chunk<TW, F8>(tc, ws_bh, ci + 5, nt_seg, lane);
     IVL_T(l6);
     IVL_TACC(lt_vmT, l1, l0); IVL_TACC(lt_wT, l2, l1); IVL_TACC(lt_iss2, l3, l2); IVL_TACC(lt_vmM, l4, l3); IVL_TACC(lt_wM, l5, l4);
@@ -1430,6 +1513,9 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
       }
     }
   }
+  if constexpr (SYNC == 2) {
+    if (vw == 0 && lane == 0) scan_abort_words<F8>(smem)[4] = 0u;
+  }
   lds_barrier();                         // PA: value tile 0 has landed (NCW = 2)
   landed(S0{});
   conv_stage(0, S0{});                   // beta v of chunk 0
@@ -1450,15 +1536,24 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   // published: the barrier carries the guarantee to the loaders (whose counted vmcnt bookkeeping a poll of their own would
   // break).  The flag word is requested one chunk before it is looked at (a device-scope load is a full memory round trip).
   unsigned int gate_val = 0;
+  bool gate_dead = false;                                            // a wait has run out: the workgroup is stopping, no more polls
   auto gate_issue = [&](int c) {
     if (c < nt_seg) gate_val = __hip_atomic_load(sy.flags + bh * SYNC_HEAD_WORDS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto gate_wait = [&](int c) {
-    if (c >= nt_seg) return;
+    if (c >= nt_seg || gate_dead) return;
     unsigned int v = gate_val;
-    for (int spin = 0; v != sy.nprod && spin < (1 << 20); ++spin) {       // bounded like scan_wait_records
+    for (int spin = 0; v != sy.nprod && spin < SYNC_SPIN_BOUND; ++spin) {   // bounded like scan_wait_records
       __builtin_amdgcn_s_sleep(4);
       v = __hip_atomic_load(sy.flags + bh * SYNC_HEAD_WORDS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((spin & 31) == 31 && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // the area has failed elsewhere
+    }
+    if (v != sy.nprod) {                                             // (wave-uniform) tell the workgroup through LDS, the host through the area
+      gate_dead = true;
+      if (lane == 0) {
+        sync_fail(sy, SYNC_E_GATE, bh, c);
+        scan_abort_words<F8>(smem)[4] = 1u;
+      }
     }
   };
   if constexpr (SYNC != 0) {
@@ -1598,10 +1693,10 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     tc.vt = lds0 + (unsigned int)Img<F8>::vt(NCW);
     tc.tub = lds0 + (unsigned int)Img<F8>::tub(NCW);
     tc.betab = lds0 + (unsigned int)Img<F8>::betab(NCW);
-    if (ridx == 0) scan_loader<0, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
-    else if (ridx == 1) scan_loader<1, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
-    else if (ridx == 2) scan_loader<2, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
-    else scan_loader<3, NCW, F8, SYNC>(ws_bh, nt_seg, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    if (ridx == 0) scan_loader<0, NCW, F8, SYNC>(ws_bh, nt_seg, smem, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else if (ridx == 1) scan_loader<1, NCW, F8, SYNC>(ws_bh, nt_seg, smem, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else if (ridx == 2) scan_loader<2, NCW, F8, SYNC>(ws_bh, nt_seg, smem, lds0, lane16, tc, lane, sy, bh, trace_wg);
+    else scan_loader<3, NCW, F8, SYNC>(ws_bh, nt_seg, smem, lds0, lane16, tc, lane, sy, bh, trace_wg);
     return;
   }
   if (role == ROLE_V) {                                         // ---- V waves ----
@@ -1631,6 +1726,7 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     };
     lds_barrier();                       // PA
     if constexpr (SYNC != 0) {
+      if (scan_aborted<F8, false>(smem)) return;     // a loader's wait failed: no output from this workgroup, flags left as they are
       if (SYNC == 1) flags_done();
     }
     lds_barrier();                       // P0
@@ -1649,6 +1745,8 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
       IVL_T(o0);
       lds_barrier();                     // T(ci): sb(ci) published, H2(ci) landed
       IVL_T(o1);
+      unsigned int gate_abort = 0u;      // long calls: the gate wave's word, read here, looked at in front of the stores
+      if constexpr (SYNC == 2) gate_abort = scan_abort_words<F8>(smem)[4];
       frag_t sb[4], fa[6];
 #pragma unroll
       for (int s = 0; s < 4; ++s) sb[s] = *(const frag_t*)(xsb + s * BLK + lanef);
@@ -1682,6 +1780,9 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
       accO[3] = mma16<F8>(vn[0], fa[4], accO[3]);
       accO[2] = mma16<F8>(vn[1], fa[3], accO[2]);
       accO[3] = mma16<F8>(vn[1], fa[5], accO[3]);
+      if constexpr (SYNC == 2) {
+        if (__builtin_amdgcn_readfirstlane(gate_abort) != 0u) return;   // a later chunk's record never came: stop storing
+      }
       if (tc0 + GC <= T) {               // full chunk (wave-uniform): four unconditional 8-byte row stores
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -1774,6 +1875,9 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     egl = *(const float*)(im + R::EGL);
   };
   lds_barrier();                         // PA
+  if constexpr (SYNC != 0) {
+    if (scan_aborted<F8, false>(smem)) return;
+  }
   lds_barrier();                         // P0
   if constexpr (TILE_OK) {
     if (tiled_in) {                      // (workgroup-uniform) own slab out of the tile: column 16 pair + j, rows 16t + 4g + r
@@ -1839,7 +1943,9 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
 
   // the final state leaves element-wise (an LDS-transposed store was measured: the workgroup barrier it needs in front of the
   // row stores -- every wave must be done with the images -- costs more than the 32 two-byte stores per lane save)
-  if (ht != nullptr) {
+  bool keep_state = ht != nullptr;
+  if constexpr (SYNC == 2) keep_state = keep_state && !scan_aborted<F8, true>(smem);   // a stopped workgroup stores no state
+  if (keep_state) {
     const size_t base = ((size_t)bh * GK + 4 * g) * GV + v0 + j;
     if (ht_dtype == IVL_F32) {
       float* hp = (float*)ht + base;
@@ -1882,56 +1988,89 @@ __global__ __launch_bounds__(64 * (2 * NCW + SCAN_NL + SCAN_NV)) void gdn_chunk_
                                              nt_seg, scale, ScanSync{});
 }
 
-// Single launch of the fused call at small grids (the benchmark's streaming step: 64 pre-pass + 128 scan workgroups on 256
-// CUs).  Blocks [0, nt_seg BH) are pre-pass workgroups (waves 8-11 leave at once), the rest scan workgroups; both kinds need
-// no more than one CU each, and every block is resident from the start: the scan side can wait for the pre-pass side
-// (scan_wait_records) without a second launch -- one launch boundary (~4.5 us inside the step's graph) and the scan's own
-// start-up (state tile, value tiles, conv of chunks 0 and 1) disappear behind the pre-pass.
+// Single launch of the fused call at small grids (the benchmark's streaming step: 2 x 64 pre-pass + 128 scan workgroups on 256
+// CUs).  The first blocks are pre-pass workgroups (waves 8-11 leave at once), the rest scan workgroups; both kinds need no more
+// than one CU each.  The scan side waits for the pre-pass side (scan_wait_records) without a second launch -- one launch
+// boundary (~4.5 us inside the step's graph) and the scan's own start-up (state tile, value tiles, conv of chunks 0 and 1)
+// disappear behind the pre-pass.  The host launches this form only when the whole grid can be resident at once (occupancy
+// query x CU count: the form's SPEED needs that; its liveness and safety do not, see scan_wait_records).
 // With BH % 8 == 0 the pre-pass workgroup of head bh gets a block id = bh (mod 8): the same die (id % 8) as the head's scan
 // workgroups, whose L2 then holds the record it is about to be asked for.
 constexpr int SINGLE_THREADS = 64 * (2 * 2 + SCAN_NL + SCAN_NV);
-constexpr int SINGLE_MAX_BLOCKS = 256;
-constexpr int G_SYNC_BYTES = IVL_GDN_SYNC_BYTES;   // flags: 64 words per head (<= 32 heads) at 0; headdone: 32 words behind them
+constexpr int G_SYNC_BYTES = IVL_GDN_SYNC_BYTES;   // flags: 64 words per head (<= 32 heads) at 0; headdone, kread: 32 words each behind them; err: 4 words
 constexpr int SYNC_MAX_HEADS = 32;
-static_assert(G_SYNC_BYTES >= 4 * (SYNC_MAX_HEADS * SYNC_HEAD_WORDS + 32 + 32), "sync area layout");   // ... kread: 32 words behind headdone
-// SPLIT (room for twice the pre-pass workgroups: 2 nt_seg BH + 8 BH <= 256): blocks [0, nt_seg BH) are the k sides (the chain
-// the scan waits for: first to be dispatched), [nt_seg BH, 2 nt_seg BH) the q sides of the chunks.
+constexpr int SYNC_ERR_WORD = SYNC_MAX_HEADS * SYNC_HEAD_WORDS + 64;
+static_assert(G_SYNC_BYTES >= 4 * (SYNC_ERR_WORD + 4), "sync area layout");
+// MODE 1, SPLIT (room for twice the pre-pass workgroups): blocks [0, BH) are the q sides of chunk 0 (the k sides of chunk 0 wait
+// for their `kread` at the very end: lower ids than their waiters), [BH, BH + nt BH) the k sides (the chain the scan waits
+// for), then the q sides of chunks 1.., then the scan workgroups.
 //
-// MODE 2, long calls (unsplit pre-pass): the 8 BH scan workgroups come FIRST and take one CU each (the host checks that the
-// device has at least twice as many), the pre-pass workgroups of the segment stream through the remaining CUs in chunk-major
-// order, and the scan consumes the records as they are published (V wave 0 gates every chunk step, three chunks ahead): the
-// pre-pass of a 4096-token call no longer runs in front of the 64 serial chunk steps but beside them.  A mode is a template
-// instance of its own: the step-shape kernel (MODE 1) carries none of the long-call code.
+// MODE 2, long calls (unsplit pre-pass): `nprep` PERSISTENT pre-pass workgroups come first and walk the segment's (chunk, head)
+// pairs in chunk-major order (pair w = id, id + nprep, ...: the records appear in the order the scan needs them), the 8 BH scan
+// workgroups behind them consume the records as they are published (V wave 0 gates every chunk step, three chunks ahead): the
+// pre-pass of a 4096-token call does not run in front of the 64 serial chunk steps but beside them.  Every workgroup of the
+// launch gets the scan's 156 KB of LDS, i.e. one CU: the host sizes nprep = resident workgroups - 8 BH (at least 8 BH).
+// A mode is a template instance of its own: the step-shape kernel (MODE 1) carries none of the long-call code.
 // MODE: 0 = small grid, whole pre-pass per chunk; 1 = small grid, split pre-pass; 2 = long call
 template <bool F8, int MODE>
 __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
     PrepFused pf, unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv, const void* h0, int h0_dtype, void* ht,
-    int ht_dtype, int T, int H, int BH, int t_seg0, int nt_seg, float scale, ScanSync sy) {
+    int ht_dtype, int T, int H, int BH, int t_seg0, int nt_seg, int nprep, float scale, ScanSync sy) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr bool SPLIT = MODE == 1, SCAN_FIRST = MODE == 2;
-  const int nside = nt_seg * BH, nprep = SPLIT ? 2 * nside : nside, nscan = 8 * BH;
+  constexpr bool SPLIT = MODE == 1, LONG = MODE == 2;
+  const int nside = nt_seg * BH;                       // (chunk, head) pairs of the segment; nprep = pre-pass workgroups of the launch
   int id = (int)blockIdx.x;
-  const bool is_scan = SCAN_FIRST ? id < nscan : id >= nprep;
-  if (!is_scan) {
+  if (id < nprep) {
     if (threadIdx.x >= 512) return;
-    if (SCAN_FIRST) id -= nscan;
-    const bool qside = SPLIT && id >= nside;
-    if (qside) id -= nside;
-    int bh, ci;
-    if (SCAN_FIRST) { ci = id / BH; bh = id % BH; }                   // chunk-major: the records appear in the order the scan needs them
-    else if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
-    else { bh = id / nt_seg; ci = id % nt_seg; }
-    unsigned int* done = sy.flags + bh * SYNC_HEAD_WORDS + ci;
-    if constexpr (!SPLIT)
-      gdn_chunk_prepare_body<F8, true, true, 0>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, nullptr);
-    else if (!qside)
-      gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh);
-    else
-      gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh);
+    if constexpr (LONG) {
+      // the front-end arguments are re-read from the kernel-argument segment in every round (scalar loads through a pointer the
+      // compiler cannot see through): held in SGPRs across the whole body they exceed the scalar register file
+      static_assert(__builtin_offsetof(PrepFused, proj) == 0, "pf is the first kernel argument");
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef __attribute__((address_space(4))) const unsigned int kernarg_word;
+      kernarg_word* kp = (kernarg_word*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+      const unsigned int* kp = (const unsigned int*)&pf;
+#endif
+      for (int w = id; w < nside; w += nprep) {        // (the publish at the end of the body is a workgroup barrier: LDS is free again)
+        asm volatile("" : "+s"(kp));
+        PrepFused pfl;
+        {
+          static_assert(sizeof(PrepFused) % 4 == 0, "copied in dwords");
+          unsigned int words[sizeof(PrepFused) / 4];
+#pragma unroll
+          for (unsigned int i = 0; i < sizeof(PrepFused) / 4; ++i) words[i] = kp[i];
+          __builtin_memcpy(&pfl, words, sizeof(PrepFused));
+        }
+        const int ci = w / BH, bh = w % BH;
+        gdn_chunk_prepare_body<F8, true, true, 0, true>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pfl, ws, T, H, t_seg0, nt_seg, 1,
+                                                  sy.flags + bh * SYNC_HEAD_WORDS + ci, nullptr, &sy);
+      }
+    } else {
+      bool qside = false;
+      if constexpr (SPLIT) {                           // ids: q sides of chunk 0 | k sides | q sides of chunks 1..
+        if (id < BH) { qside = true; }
+        else if (id < BH + nside) { id -= BH; }
+        else { qside = true; id -= nside; }            // -> [BH, nside): chunk >= 1 in the numbering below
+      }
+      int bh, ci;
+      if ((BH & 7) == 0) { bh = (id & 7) + 8 * ((id >> 3) / nt_seg); ci = (id >> 3) % nt_seg; }
+      else { bh = id / nt_seg; ci = id % nt_seg; }
+      if (SPLIT && qside) {                            // q sides are numbered chunk-major: id = ci BH + bh (chunk 0 first)
+        ci = id / BH; bh = id % BH;
+      }
+      unsigned int* done = sy.flags + bh * SYNC_HEAD_WORDS + ci;
+      if constexpr (!SPLIT)
+        gdn_chunk_prepare_body<F8, true, true, 0>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, nullptr, &sy);
+      else if (!qside)
+        gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh, &sy);
+      else
+        gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh, &sy);
+    }
   } else {
-    if (!SCAN_FIRST) id -= nprep;
-    gdn_chunk_scan_body<2, F8, true, SCAN_FIRST ? 2 : 1>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0, nt_seg,
-                                                         scale, sy);
+    id -= nprep;
+    gdn_chunk_scan_body<2, F8, true, LONG ? 2 : 1>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0, nt_seg,
+                                                   scale, sy);
   }
 }
 
@@ -1952,20 +2091,38 @@ static void scan_set_attr() {
                             scan_lds_bytes(NCW, F8));
 }
 static int g_cu_count[64];
-static int device_cu_count() {
+static int g_resident[64][2];                       // [device][F8]: workgroups of the single-launch kernels that can be resident at once
+static unsigned int* g_host_status[64];             // [device]: two words of pinned host memory the kernels report a failed wait in
+static unsigned int* g_host_status_dev[64];         // ... as the device addresses them
+static int device_index() {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  return g_cu_count[dev & 63];
+  return dev & 63;
 }
-// dynamic-LDS opt-in, once per device (hipFuncSetAttribute acts on the current device)
+static int device_cu_count() { return g_cu_count[device_index()]; }
+// Workgroups of gdn_chunk_single_kernel<F8, .> that the device holds at once: occupancy query x CU count, the smallest over the
+// three modes (768 threads and ~156 KB of LDS: one per CU).  ivl_gdn_resident_blocks overrides it (0 = never a single launch:
+// the switch back to the two-launch form; a small number stands for a small or partitioned device).
+static int g_resident_override = -1;
+static int resident_blocks(bool f8) {
+  const int ov = __atomic_load_n(&g_resident_override, __ATOMIC_RELAXED);
+  if (ov >= 0) return ov;
+  return g_resident[device_index()][f8 ? 1 : 0];
+}
+template <bool F8, int MODE>
+static int single_occupancy(int lds, int cus) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gdn_chunk_single_kernel<F8, MODE>, SINGLE_THREADS, (size_t)lds) != hipSuccess) nb = 0;
+  return nb * cus;
+}
+// dynamic-LDS opt-in, occupancy and the host status word, once per device (hipFuncSetAttribute acts on the current device)
 static void gdn_chunk_init_device() {
   static std::once_flag once[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::call_once(once[dev & 63], [dev] {
+  const int dev = device_index();
+  std::call_once(once[dev], [dev] {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    g_cu_count[dev & 63] = cus;
+    g_cu_count[dev] = cus;
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<false, false>, attr, P_BYTES);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, false>, attr, P_BYTES);
@@ -1973,14 +2130,48 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_prepare_kernel<true, true>, attr, P_BYTES);
     scan_set_attr<4, false, false>(); scan_set_attr<2, false, false>(); scan_set_attr<4, true, false>(); scan_set_attr<2, true, false>();
     scan_set_attr<4, false, true>(); scan_set_attr<2, false, true>(); scan_set_attr<4, true, true>(); scan_set_attr<2, true, true>();
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 0>, attr, scan_lds_bytes(2, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 1>, attr, scan_lds_bytes(2, false));
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 2>, attr, scan_lds_bytes(2, false));
+    const int lds16 = scan_lds_bytes(2, false);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 0>, attr, lds16);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 1>, attr, lds16);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 2>, attr, lds16);
     const int lds8 = scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES;
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 0>, attr, lds8);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 1>, attr, lds8);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 2>, attr, lds8);
+    auto min3 = [](int a, int b, int c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
+    g_resident[dev][0] = min3(single_occupancy<false, 0>(lds16, cus), single_occupancy<false, 1>(lds16, cus), single_occupancy<false, 2>(lds16, cus));
+    g_resident[dev][1] = min3(single_occupancy<true, 0>(lds8, cus), single_occupancy<true, 1>(lds8, cus), single_occupancy<true, 2>(lds8, cus));
+    // the status word: 64 bytes of pinned, device-mapped host memory for the life of the process (the one thing the library
+    // allocates; without it a failed wait is still recorded in the sync area and found by ivl_gdn_sync_status)
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hp != nullptr) {
+      __builtin_memset(hp, 0, 64);
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        g_host_status[dev] = (unsigned int*)hp;
+        g_host_status_dev[dev] = (unsigned int*)dp;
+      } else {
+        (void)hipHostFree(hp);
+      }
+    }
+    (void)hipGetLastError();
   });
+}
+static const char* sync_code_name(unsigned int code) {
+  switch (code & 0xffu) {
+    case SYNC_E_START: return "scan workgroup: the records it waits for at its start were not published in time";
+    case SYNC_E_GATE: return "scan workgroup (long call): a later chunk's record was not published in time";
+    case SYNC_E_KREAD: return "pre-pass k side: the q side did not read the old conv state in time";
+    default: return "unknown code";
+  }
+}
+// the host-visible status of the current device: 0 = healthy
+static unsigned int host_status(unsigned int* where) {
+  const unsigned int* hs = g_host_status[device_index()];
+  if (hs == nullptr) return 0u;
+  const unsigned int code = __atomic_load_n(hs, __ATOMIC_RELAXED);
+  if (where != nullptr) *where = __atomic_load_n(hs + 1, __ATOMIC_RELAXED);
+  return code;
 }
 
 extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V) {
@@ -2017,31 +2208,36 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
     sv.v = (const bf16_t*)v; sv.ld = (long long)H * GV; sv.col0 = 0; sv.w = nullptr; sv.st_in = nullptr; sv.st_out = nullptr;
   }
   const int BH = B * H;
+  // Single-launch forms: the caller handed over a healthy sync area and the grid can be resident at once (the forms' speed needs
+  // that; IVL_GDN_RESIDENT_BLOCKS = 0 switches them off).  NT <= 63: one poll lane per chunk plus the error-word lane.
+  const int resident = sync != nullptr ? resident_blocks(F8) : 0;
   const bool can_sync = pf != nullptr && sync != nullptr && ncw == 2 && BH <= SYNC_MAX_HEADS;
-  bool single = can_sync && NT * BH + (16 / 2) * BH <= SINGLE_MAX_BLOCKS;
-  // long calls: one launch per segment with the scan workgroups first -- needs twice as many CUs as scan workgroups
-  bool overlap = can_sync && !single && 2 * 8 * BH <= device_cu_count();
+  bool single = can_sync && NT <= 63 && NT * BH + (16 / 2) * BH <= resident;
+  // long calls: one launch per segment, persistent pre-pass workgroups beside the scan workgroups -- at least as many of them
+  bool overlap = can_sync && !single && 2 * 8 * BH <= resident;
 #ifdef IVL_TRACE
   single = single && g_gdn_single != 0;
   overlap = overlap && g_gdn_single != 0 && g_gdn_single != 3;
 #endif
   ScanSync sy;
   if (can_sync) {
-    sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.BH = BH; sy.nprod = 1u;
+    sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.err = sync + SYNC_ERR_WORD;
+    sy.host_err = g_host_status_dev[device_index()];
+    sy.BH = BH; sy.nprod = 1u;
   }
   const int lds1 = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
   if (single) {
-    bool split = 2 * NT * BH + 8 * BH <= SINGLE_MAX_BLOCKS;
+    bool split = 2 * NT * BH + 8 * BH <= resident;
 #ifdef IVL_TRACE
     split = split && g_gdn_single != 2;
 #endif
     sy.nprod = split ? 2u : 1u;
     if (split)
       hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 1>), dim3(2 * NT * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
-                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, scale, sy);
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, 2 * NT * BH, scale, sy);
     else
       hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 0>), dim3(NT * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
-                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, scale, sy);
+                         (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, NT * BH, scale, sy);
     return check_launch("ivl_gdn_chunk_fused_fwd(single launch)");
   }
   for (int c0 = 0; c0 < NT; c0 += segc) {
@@ -2052,8 +2248,11 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
       const int hin_dt = first ? h0_dtype : IVL_F32;
       void* hout = last ? ht : (void*)carry;
       const int hout_dt = last ? ht_dtype : IVL_F32;
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nseg * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
-                         (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, scale, sy);
+      int nprep = resident - 8 * BH;                               // persistent pre-pass workgroups: what the chip holds beside the scan
+      if (nprep > nseg * BH) nprep = nseg * BH;
+      if ((BH & 7) == 0) nprep -= nprep % BH;                      // whole rounds of heads: a head's records stay on its die (id % 8)
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nprep + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
+                         (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, nprep, scale, sy);
       int rc = check_launch("ivl_gdn_chunk_fused_fwd(overlapped launch)");
       if (rc != IVL_OK) return rc;
       continue;
@@ -2134,6 +2333,14 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
               "ivl_gdn_chunk_fused_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
   IVL_REQUIRE(sync == nullptr || ((size_t)sync & 15) == 0, IVL_ERR_INVALID_ARG, "ivl_gdn_chunk_fused_fwd: sync area must be 16-byte aligned");
   gdn_chunk_init_device();
+  if (sync != nullptr) {
+    unsigned int where = 0;
+    const unsigned int code = host_status(&where);
+    IVL_REQUIRE(code == 0u, IVL_ERR_SYNC,
+                "ivl_gdn_chunk_fused_fwd: an earlier single-launch call on this device failed (code %u: %s; head %u, chunk %u): its "
+                "outputs and states are incomplete. ivl_gdn_sync_reset() re-arms the sync area",
+                code, sync_code_name(code), where >> 16, where & 0xffffu);
+  }
   PrepFused pf;
   pf.proj = (const bf16_t*)proj; pf.ld = ld;
   pf.col_q = col_q; pf.col_k = col_k; pf.col_v = col_v; pf.col_a = col_a; pf.col_b = col_b;
@@ -2146,4 +2353,47 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
                                   (unsigned char*)workspace, (unsigned int*)sync, (hipStream_t)stream);
   return gdn_chunk_launch<false>(nullptr, nullptr, nullptr, nullptr, nullptr, &pf, o, h0, h0_dtype, ht, ht_dtype, B, T, H, scale, 1,
                                  (unsigned char*)workspace, (unsigned int*)sync, (hipStream_t)stream);
+}
+
+// Status of the single-launch forms on the current device: IVL_OK, or IVL_ERR_SYNC when a wait inside a launch ran out (the
+// kernels report it through a pinned host word: no stream work, no synchronisation -- what has been reported so far).
+// `sync` != NULL additionally reads the area's own error word from the device (a blocking copy behind `stream`: never during
+// capture), which also covers a device whose host word could not be allocated.
+extern "C" int ivl_gdn_sync_status(const void* sync, void* stream) {
+  gdn_chunk_init_device();
+  unsigned int where = 0;
+  unsigned int code = host_status(&where);
+  if (code == 0u && sync != nullptr) {
+    unsigned int w[2] = {0u, 0u};
+    hipError_t e = hipMemcpyAsync(w, (const unsigned int*)sync + SYNC_ERR_WORD, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    IVL_REQUIRE(e == hipSuccess, IVL_ERR_LAUNCH, "ivl_gdn_sync_status: %s", hipGetErrorString(e));
+    code = w[0]; where = w[1];
+  }
+  IVL_REQUIRE(code == 0u, IVL_ERR_SYNC, "ivl_gdn_sync_status: a wait inside a single-launch call ran out (code %u: %s; head %u, chunk %u)",
+              code, sync_code_name(code), where >> 16, where & 0xffffu);
+  return IVL_OK;
+}
+
+// Re-arm: zero the area (behind `stream`) and the device's host status word.  Also the way to initialise a fresh area.
+extern "C" int ivl_gdn_sync_reset(void* sync, void* stream) {
+  IVL_REQUIRE(sync != nullptr && ((size_t)sync & 15) == 0, IVL_ERR_INVALID_ARG, "ivl_gdn_sync_reset: sync area must be a 16-byte aligned device pointer");
+  gdn_chunk_init_device();
+  const hipError_t e = hipMemsetAsync(sync, 0, G_SYNC_BYTES, (hipStream_t)stream);
+  IVL_REQUIRE(e == hipSuccess, IVL_ERR_LAUNCH, "ivl_gdn_sync_reset: %s", hipGetErrorString(e));
+  unsigned int* hs = g_host_status[device_index()];
+  if (hs != nullptr) {
+    __atomic_store_n(hs + 1, 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(hs, 0u, __ATOMIC_RELAXED);
+  }
+  return IVL_OK;
+}
+
+// How many workgroups of the single-launch kernels the library takes to be resident at once on the current device (what gates
+// the single-launch forms).  override >= 0 replaces the occupancy-derived number process-wide (0: always two launches),
+// override < 0 restores it; returns the number in force for bf16 operands.
+extern "C" int ivl_gdn_resident_blocks(int override_blocks) {
+  gdn_chunk_init_device();
+  __atomic_store_n(&g_resident_override, override_blocks < 0 ? -1 : override_blocks, __ATOMIC_RELAXED);
+  return resident_blocks(false);
 }

@@ -345,6 +345,7 @@ class GraphedStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.hidden = self.logits = None
         self._warmup = warmup
+        self._sync: Optional[torch.Tensor] = None
 
     def _run(self):
         h, lg = self.model(inputs_embeds=self.inputs_embeds, position_ids=self.position_ids,
@@ -358,15 +359,20 @@ class GraphedStep:
         self.cache.ensure_started()          # a replayed graph always reads the cache tensors
         saved = self.cache.clone()
         saved_pos = self.position_ids.clone()
+        # the graph owns the flag words of its single-launch GDN calls (ops.gdn_sync_scope): it may be replayed beside eager
+        # calls or other graphs without sharing them
+        if self._sync is None:
+            self._sync = ops.new_gdn_sync_area(self.inputs_embeds.device)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s), torch.no_grad():
-            for _ in range(self._warmup):
-                self._run()
-        torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.hidden, self.logits = self._run()
+        with ops.gdn_sync_scope(self._sync):
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(self._warmup):
+                    self._run()
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.hidden, self.logits = self._run()
         self.cache.copy_from(saved)
         self.position_ids.copy_(saved_pos)
 
@@ -385,6 +391,7 @@ class GraphedStep:
             self.inputs_embeds.copy_(inputs_embeds)
         self.graph.replay()
         self.cache.advance(self.T)
+        ops.gdn_sync_check(self.inputs_embeds.device)    # free (a host word): a failed in-launch wait of an EARLIER replay raises here
         return self.hidden, self.logits
 
 

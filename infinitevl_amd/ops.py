@@ -13,7 +13,9 @@ There is no CPU path: tensors must live on a ROCm device and the shared library 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import threading
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -191,22 +193,103 @@ def chunk_gated_delta_rule(
     return (o.transpose(1, 2) if head_first else o), ht
 
 
-_GDN_SYNC: Dict[int, torch.Tensor] = {}
+_GDN_SYNC: Dict[Tuple[int, object], torch.Tensor] = {}
+_GDN_SYNC_SCOPE = threading.local()      # .areas: {device index: area} inside `with gdn_sync_scope(area)`
 _GDN_SINGLE_LAUNCH = True      # tests switch it off to compare the single-launch form with the two-launch form
 
 
+def new_gdn_sync_area(device) -> torch.Tensor:
+    """A fresh, zeroed sync area for ivl_gdn_chunk_fused_fwd's single-launch forms (include/ivl_hip.h).  Whoever may issue
+    calls CONCURRENTLY with others (a stream of its own, a captured hipGraph that is replayed beside other work) owns one."""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("a GDN sync area cannot be created during hipGraph capture; create it (or run a warm-up step) first")
+    area = torch.zeros(_lib.IVL_GDN_SYNC_BYTES, dtype=torch.uint8, device=device)
+    _GDN_SYNC[(area.device.index, id(area))] = area          # known to gdn_sync_check(deep=True) / gdn_sync_reset
+    return area
+
+
+@contextlib.contextmanager
+def gdn_sync_scope(area: torch.Tensor):
+    """Calls issued by this thread inside the scope use `area` (the harness captures every graph inside a scope with an area
+    the graph object owns: graphs never share flag words with each other or with eager calls)."""
+    areas = getattr(_GDN_SYNC_SCOPE, "areas", None)
+    if areas is None:
+        areas = _GDN_SYNC_SCOPE.areas = {}
+    dev = area.device.index
+    prev = areas.get(dev)
+    areas[dev] = area
+    try:
+        yield area
+    finally:
+        if prev is None:
+            areas.pop(dev, None)
+        else:
+            areas[dev] = prev
+
+
 def _gdn_sync_area(device: torch.device) -> torch.Tensor:
-    """The flag words of ivl_gdn_chunk_fused_fwd's single-launch form (include/ivl_hip.h): zeroed here once, then owned by
-    the library (every launch leaves it all-zero).  One per device: the package issues its calls on one stream."""
+    """The flag words of ivl_gdn_chunk_fused_fwd's single-launch forms: zeroed here once, then owned by the library (every
+    launch leaves it all-zero).  Resolution: the enclosing gdn_sync_scope, else one area per (device, STREAM) for eager calls
+    -- two calls that may run concurrently must not share flag words, and the package issues a call on the caller's current
+    stream -- else, for a capture outside any scope, the device's one area for such graphs (they must not be replayed
+    concurrently with each other; created together with the first eager area, i.e. by the warm-up a capture needs anyway)."""
     device = torch.device(device)
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    area = _GDN_SYNC.get(dev)
+    areas = getattr(_GDN_SYNC_SCOPE, "areas", None)
+    if areas:
+        area = areas.get(dev)
+        if area is not None:
+            return area
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev, "graphs") if capturing else (dev, int(torch.cuda.current_stream(device).cuda_stream))
+    area = _GDN_SYNC.get(key)
     if area is None:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError("the GDN sync area would have to be created during hipGraph capture; run a warm-up step first")
         area = torch.zeros(_lib.IVL_GDN_SYNC_BYTES, dtype=torch.uint8, device=device)
-        _GDN_SYNC[dev] = area
+        _GDN_SYNC[key] = area
+        if (dev, "graphs") not in _GDN_SYNC:
+            _GDN_SYNC[(dev, "graphs")] = torch.zeros(_lib.IVL_GDN_SYNC_BYTES, dtype=torch.uint8, device=device)
     return area
+
+
+def gdn_resident_blocks(override: int = -1) -> int:
+    """Workgroups of the single-launch GDN kernels taken to be resident at once on the current device (what gates the
+    single-launch forms: ivl_gdn_resident_blocks).  `override` >= 0 replaces the occupancy-derived number process-wide (0 =
+    always the two-launch form; the environment variable IVL_GDN_RESIDENT_BLOCKS sets it when the package is imported),
+    < 0 restores the query.  Returns the number in force."""
+    return _lib.load().ivl_gdn_resident_blocks(int(override))
+
+
+def gdn_sync_check(device=None, *, deep: bool = False) -> None:
+    """Raise IvlError(IVL_ERR_SYNC) if a wait inside a single-launch GDN call on `device` ran out (a broken contract: shared sync
+    area, starved launch).  Free by default -- it reads the host-visible status word the kernels report through, so it sees
+    failures of kernels that have FINISHED (call it behind a synchronisation point); `deep=True` also copies every sync area's
+    own error word back (blocking).  The harness calls it after graph replays; every eager gdn_chunk_fused call checks it too
+    (inside the C entry point)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        _lib.check(lib.ivl_gdn_sync_status(None, None))
+        if deep:
+            dev = device.index if device.index is not None else torch.cuda.current_device()
+            for (d, _), area in list(_GDN_SYNC.items()):
+                if d == dev:
+                    _lib.check(lib.ivl_gdn_sync_status(_p(area), _stream(area)))
+
+
+def gdn_sync_reset(device=None) -> None:
+    """Re-arm every sync area of `device` after a reported failure (the outputs / states of the failed call are incomplete:
+    the caller restarts from a known cache state)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        torch.cuda.synchronize(device)
+        for (d, _), area in list(_GDN_SYNC.items()):
+            if d == dev:
+                _lib.check(lib.ivl_gdn_sync_reset(_p(area), _stream(area)))
+        torch.cuda.synchronize(device)
 
 
 def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv_states_out, A_log32, dt_bias32,

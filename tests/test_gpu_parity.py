@@ -1373,13 +1373,8 @@ def test_gdn_chunk_fused_rejects_a_misaligned_sync_area():
     A32, dt32 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     good = ops._gdn_sync_area(torch.device(DEV))
     bad = torch.zeros(good.numel() + 16, dtype=torch.uint8, device=DEV)[4:]
-    key = [k for k, v in ops._GDN_SYNC.items() if v is good][0]
-    ops._GDN_SYNC[key] = bad
-    try:
-        with pytest.raises(ValueError):
-            ops.gdn_chunk_fused(proj, cols, cw, [None] * 3, [None] * 3, A32, dt32, H, K, V)
-    finally:
-        ops._GDN_SYNC[key] = good
+    with ops.gdn_sync_scope(bad), pytest.raises(ValueError):
+        ops.gdn_chunk_fused(proj, cols, cw, [None] * 3, [None] * 3, A32, dt32, H, K, V)
 
 
 def test_decode_step_uses_weight_stream_and_matches_gemm_path():
@@ -1582,21 +1577,23 @@ def test_gdn_chunk_with_fused_front_end_is_bit_identical(B, T, hist, st_dtype):
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("B,T,hist,mma", [(1, 256, True, None), (1, 512, True, None), (1, 64, False, None), (1, 300, True, None),
-                                          (1, 7, True, None), (1, 256, True, "fp8_e4m3"), (2, 128, True, None),
-                                          # long calls: scan workgroups first, records awaited chunk by chunk; two workspace segments
-                                          (1, 1000, True, None), (1, 4300, True, None)])
-def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma):
+@pytest.mark.parametrize("B,T,hist,mma,H", [(1, 256, True, None, 16), (1, 512, True, None, 16), (1, 64, False, None, 16), (1, 300, True, None, 16),
+                                            (1, 7, True, None, 16), (1, 256, True, "fp8_e4m3", 16), (2, 128, True, None, 16),
+                                            # long calls: persistent pre-pass workgroups beside the scan, records awaited chunk by chunk; two workspace segments
+                                            (1, 1000, True, None, 16), (1, 4300, True, None, 16),
+                                            # B*H not a multiple of 8: a head's pre-pass and scan workgroups sit on DIFFERENT dies (records cross L2s)
+                                            (1, 256, True, None, 3), (3, 200, True, None, 5), (1, 1000, True, None, 6), (1, 8292, True, None, 1)])
+def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma, H):
     """ivl_gdn_chunk_fused_fwd with a sync area (pre-pass and scan workgroups of ONE launch, the scan side waiting on flags) must
     equal the two-launch form bit for bit -- outputs, final state, conv states -- call after call (the launch clears its own
     flags: the area is all-zero afterwards) and when replayed from a hipGraph."""
     from infinitevl_amd import ops
-    H, K, V = 16, 128, 256
+    K, V = 128, 256
     Dq, Dk, Dv = H * K, H * K, H * V
     g_ = torch.Generator(device=DEV).manual_seed(B * 77 + T)
     rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
     cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
-    ld = cols[4] + H
+    ld = (cols[4] + H + 7) // 8 * 8                                      # rows are 16-byte aligned
     cw = [rn(D_, 1, 4) * 0.5 for D_ in (Dq, Dk, Dv)]
     A32, dt32 = torch.randn(H, device=DEV, generator=g_), torch.randn(H, device=DEV, generator=g_)
 
@@ -1656,6 +1653,148 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma):
         for a, b_ in zip(so, so_ref):
             assert torch.equal(a, b_)
     assert int(area.view(torch.int32).abs().sum()) == 0
+
+
+def _gdn_fused_case(T, H=16, B=1, seed=0):
+    """inputs of one fused GDN call + a runner (single-launch form or two launches)"""
+    from infinitevl_amd import ops
+    K, V = 128, 256
+    Dq, Dk, Dv = H * K, H * K, H * V
+    g_ = torch.Generator(device=DEV).manual_seed(9000 + seed + T)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+    cw = [rn(D_, 1, 4) * 0.5 for D_ in (Dq, Dk, Dv)]
+    A32, dt32 = torch.randn(H, device=DEV, generator=g_), torch.randn(H, device=DEV, generator=g_)
+    proj = rn(B, T, cols[4] + H)
+    cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+    h0 = bf(torch.randn(B, H, K, V, device=DEV, generator=g_) * 0.1)
+
+    def run(single, ht_fill=None):
+        so = [c.clone() for c in cs]
+        ht = torch.zeros_like(h0) if ht_fill is None else torch.full_like(h0, ht_fill)
+        ops._GDN_SINGLE_LAUNCH = single
+        try:
+            o = ops.gdn_chunk_fused(proj, cols, cw, so, so, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht)
+        finally:
+            ops._GDN_SINGLE_LAUNCH = True
+        return o, ht, so
+    return run
+
+
+def _gdn_kernel_names(fn):
+    """names of the GDN chunk kernels `fn` launches (profiler activity records)"""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return [e.name for e in prof.events() if "gdn_chunk" in e.name]
+
+
+def test_gdn_single_launch_is_gated_on_real_occupancy():
+    """The single-launch forms are taken only when the occupancy query says the grid can be resident at once
+    (ivl_gdn_resident_blocks stands in for a smaller device): a too-small device takes the two-launch form, a device with room
+    for the unsplit grid only takes the unsplit form -- always with the same bits."""
+    from infinitevl_amd import ops
+    run = _gdn_fused_case(256)
+    ref = run(False)
+
+    def same(out, r=ref):
+        return torch.equal(out[0], r[0]) and torch.equal(out[1], r[1]) and all(torch.equal(a, b_) for a, b_ in zip(out[2], r[2]))
+    try:
+        assert ops.gdn_resident_blocks(-1) == 256, "a whole MI355X holds one single-launch workgroup per CU"
+        names = _gdn_kernel_names(lambda: run(True))
+        assert len(names) == 1 and "gdn_chunk_single_kernel" in names[0] and "kernel<false, 1>" in names[0], names      # split pre-pass
+        ops.gdn_resident_blocks(200)                                # 64 + 128 workgroups fit, 2 x 64 + 128 do not
+        names = _gdn_kernel_names(lambda: same(run(True)) or pytest.fail("unsplit single launch differs"))
+        assert len(names) == 1 and "kernel<false, 0>" in names[0], names
+        ops.gdn_resident_blocks(100)                                # not even the scan workgroups fit: two launches
+        names = _gdn_kernel_names(lambda: same(run(True)) or pytest.fail("two-launch fallback differs"))
+        assert len(names) == 2 and any("prepare" in n for n in names) and any("scan_kernel" in n for n in names), names
+        ops.gdn_resident_blocks(0)
+        assert len(_gdn_kernel_names(lambda: run(True))) == 2
+        # long call: needs twice the scan workgroups; with less it is prepare + scan per segment
+        run_long = _gdn_fused_case(1000)
+        ref_long = run_long(False)
+        ops.gdn_resident_blocks(255)                                # 127 -> 112 persistent pre-pass workgroups (whole rounds of heads)
+        assert same(run_long(True), ref_long)
+        ops.gdn_resident_blocks(160)                                # 128 scan + 32 < 2 x 128
+        names = _gdn_kernel_names(lambda: run_long(True))
+        assert len(names) == 2 and not any("single" in n for n in names), names
+        ops.gdn_resident_blocks(-1)
+        names = _gdn_kernel_names(lambda: run_long(True))
+        assert len(names) == 1 and "kernel<false, 2>" in names[0], names
+    finally:
+        ops.gdn_resident_blocks(-1)
+
+
+@pytest.mark.parametrize("T,chunk", [(256, 1), (1000, 0), (1000, 10)])
+def test_gdn_single_launch_reports_a_wait_that_runs_out(T, chunk):
+    """A broken contract (here: a flag word that something else has written) must not produce silent garbage: the bounded wait
+    runs out, the workgroups that waited store NOTHING (the head's final state keeps the caller's bytes), the failure is
+    reported (ops.gdn_sync_check, and IVL_ERR_SYNC from the next call), queued launches stop at once, and after
+    ops.gdn_sync_reset the area works again."""
+    from infinitevl_amd import ops
+    from infinitevl_amd._lib import IVL_ERR_SYNC, IvlError
+    run = _gdn_fused_case(T)
+    ref = run(False)
+    area = ops.new_gdn_sync_area(DEV)
+    try:
+        with ops.gdn_sync_scope(area):
+            assert torch.equal(run(True)[0], ref[0])
+            torch.cuda.synchronize()
+            ops.gdn_sync_check(DEV, deep=True)
+            area.view(torch.int32)[64 * 2 + chunk] = 7            # head 2: the flag of `chunk` can never equal the producer count
+            o, ht, _ = run(True, ht_fill=3.0)
+            run(True)                                              # queued behind the failing launch: must give up at once
+            torch.cuda.synchronize()
+            assert bool((ht[0, 2] == 3.0).all()), "head 2 must not store a state computed from records it never saw"
+            for h in (0, 1, 3, 15):
+                assert torch.equal(ht[0, h], ref[1][0, h])         # the other heads are not affected
+            with pytest.raises(IvlError) as ei:
+                ops.gdn_sync_check(DEV)
+            assert ei.value.code == IVL_ERR_SYNC and "head 2" in str(ei.value)
+            with pytest.raises(IvlError):
+                run(True)                                          # refused: nothing is launched on a failed area
+            ops.gdn_sync_reset(DEV)
+            ops.gdn_sync_check(DEV, deep=True)
+            out = run(True)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+            assert int(area.view(torch.int32).abs().sum()) == 0
+    finally:
+        torch.cuda.synchronize()
+        ops.gdn_sync_reset(DEV)
+        ops._GDN_SYNC.pop((area.device.index, id(area)), None)
+
+
+def test_gdn_single_launch_under_a_co_running_stream():
+    """Single-launch forms (step shape and long calls) while a second stream keeps the chip full of streaming kernels of uneven
+    length: bit-equal to the two-launch form, no wait runs out, flags left cleared (tools/gdn_sync_stress.py)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "256,1000,4300", "--iters", "40", "--co-stream"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "GDN_SYNC_STRESS PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_gdn_single_launch_two_processes_on_one_gpu():
+    """Two processes on this one GPU, both issuing long single-launch calls (T = 1000 / 4300: 128 scan + 128 persistent pre-pass
+    workgroups each, one CU per workgroup) and step-shape calls at the same time: neither can be resident in full.  A workgroup
+    only waits for workgroups with lower block ids, so both make progress; results bit-equal to the two-launch form in both."""
+    import subprocess
+    import sys as _sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        bar = os.path.join(td, "go")
+        procs = [subprocess.Popen([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "1000,4300,256", "--iters", "40",
+                                   "--barrier-file", bar, "--nprocs", "2", "--seed", str(i)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
+        outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "GDN_SYNC_STRESS PASS" in so, (so[-2000:], se[-2000:])
 
 
 @pytest.mark.parametrize("M,N,K,glu,res", [(1, 12320, 2048, False, True), (1, 2560, 2048, False, True), (1, 11008, 2048, True, True),
