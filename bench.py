@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the bulk-prefill leg (configs[3]: 4096-token calls at >= 128K context)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (e4m3) leg (BASELINE.json configs[4])")
+    ap.add_argument("--sp-tokens", type=int, default=4096, help="N > 1: tokens per rank of the sequence-parallel prefill leg")
+    ap.add_argument("--no-sp", action="store_true", help="N > 1: skip the sequence-parallel prefill leg (SURVEY.md 8f-4)")
     return ap.parse_args()
 
 
@@ -387,11 +389,17 @@ def kernel_timings(device, chunk, window, only=None, live_prefill=None, live_dec
     Hv, dv, frames, per = 16, 80, 8, 1024
     qkv = rn(frames * per, 3, Hv, dv)
     vcos, vsin = (torch.randn(frames * per, dv, device=device, generator=g_) for _ in range(2))
+    # a window layer does 4 * 80 * 64 flops per byte-pair of its q / k / v / o rows: ~41 flop per byte of HBM traffic, far
+    # left of the ridge (2,500 TFLOP/s / 8 TB/s = 312 flop / byte) -- HBM-bound: q, k, v read + o written (bf16) + the fp32
+    # rotary tables; the full-attention layer (1024-patch segments: 16x the flops on the same bytes) is MFMA-bound
+    vis_bytes = frames * per * (4 * Hv * dv * 2 + 2 * dv * 4)
     for tag, seg in (("window layer, 64-patch segments", 64), ("full layer, 1024-patch segments", 1024)):
         cu = torch.arange(0, frames * per + 1, seg, dtype=torch.int32, device=device)
+        vis_flops = 4.0 * dv * Hv * (frames * per // seg) * seg * seg
+        hbm_bound = vis_flops / vis_bytes < MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         add(f"vision_attn({tag})@8 frames", lambda i, cu=cu, seg=seg: ops.vision_window_attention(
-            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg, rope=(vcos, vsin)), 20, "other", 0, "mfma",
-            4.0 * dv * Hv * (frames * per // seg) * seg * seg)
+            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, seg, rope=(vcos, vsin)), 20, "other", 0,
+            "hbm" if hbm_bound else "mfma", vis_bytes if hbm_bound else vis_flops)
     return res
 
 
@@ -579,6 +587,55 @@ def main():
             print(f"[bench] torch.profiler unavailable for the decode graph ({type(e).__name__}: {e})", file=sys.stderr)
     mem_gb = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
+    # ---- sequence-parallel prefill leg (N > 1; reported beside the headline, never mixed into `value`): ONE
+    #      sequence of N x sp_tokens tokens cut into N consecutive segments, rank r runs the whole stack on segment r and hands
+    #      every layer's carried state to rank r + 1 (point-to-point: device tensors over xGMI under RCCL, host-staged under the
+    #      gloo debug backend).  Checked on the last rank against its own single-rank run of the same call sequence.
+    sp = None
+    if world > 1 and not args.no_sp:
+        Ts = args.sp_tokens
+        gsp = torch.Generator(device=device).manual_seed(4242)           # the same sequence on every rank
+        xs_all = (torch.randn(1, world * Ts, cfg.hidden_size, device=device, generator=gsp) * 0.02).to(torch.bfloat16)
+        first, last_tok = ivd.segment_bounds(world * Ts, rank, world)
+        cache_sp = model.allocate_inference_cache(1)
+        sp_ms = []
+        with torch.no_grad():
+            for rep in range(2):                                          # rep 0: communicator set-up and warm-up, rep 1: timed
+                cache_sp.reset()
+                ivd.barrier()
+                torch.cuda.synchronize()
+                tA = time.perf_counter()
+                _, lg_sp = ivd.sequence_parallel_prefill(model, xs_all[:, first:last_tok], cache_sp, first, rank, world, logits_to_keep=1)
+                torch.cuda.synchronize()
+                ivd.barrier()
+                sp_ms.append(ivd.max_over_ranks((time.perf_counter() - tA) * 1e3, device))
+            check = {"equal": None, "max_abs_diff": None}
+            if rank == world - 1:                                         # the single-rank run of the same call sequence
+                cache_1 = model.allocate_inference_cache(1)
+                tB = time.perf_counter()
+                for r_ in range(world):
+                    f_, l_ = ivd.segment_bounds(world * Ts, r_, world)
+                    pos_ = torch.arange(f_, l_, device=device)[None, None, :].expand(3, 1, l_ - f_).contiguous()
+                    _, lg_1 = model(inputs_embeds=xs_all[:, f_:l_], position_ids=pos_, past_key_values=cache_1, logits_to_keep=1)
+                torch.cuda.synchronize()
+                one_rank_ms = (time.perf_counter() - tB) * 1e3
+                check = {"equal": bool(torch.equal(lg_sp, lg_1)), "max_abs_diff": float((lg_sp.float() - lg_1.float()).abs().max()),
+                         "single_rank_ms": one_rank_ms, "finite": bool(torch.isfinite(lg_sp.float()).all())}
+                del cache_1
+            box = [check]
+            torch.distributed.broadcast_object_list(box, src=world - 1)
+            check = box[0]
+        backend = torch.distributed.get_backend()
+        sp = {"workload": f"sequence-parallel prefill of ONE {world * Ts}-token sequence over {world} ranks ({Ts} tokens per rank), "
+                          f"per-layer carried-state hand-off rank r -> r + 1 (SURVEY.md 8f-4; the reference has no such path)",
+              "tokens": world * Ts, "ms": sp_ms[-1], "ms_first_run_with_setup": sp_ms[0], "tok_s": world * Ts / (sp_ms[-1] * 1e-3),
+              "backend": backend, "device_p2p": backend == "nccl",
+              "transport": "device tensors, batch_isend_irecv (RCCL over xGMI)" if backend == "nccl" else "host-staged (gloo debug backend)",
+              "last_token_logits_equal_single_rank_run": check["equal"], "max_abs_diff": check["max_abs_diff"],
+              "single_rank_ms_same_calls": check.get("single_rank_ms"), "speedup_vs_single_rank": (check["single_rank_ms"] / sp_ms[-1]) if check.get("single_rank_ms") else None,
+              "logits_finite": check.get("finite")}
+        del cache_sp, xs_all
+
     # ---- fp8 leg (rank 0, reported beside the headline, never mixed into `value`): BASELINE.json configs[4] -- the same
     #      steady-state streaming step and decode step with e4m3 operands in the GDN chunk scan / SWA decode step
     fp8 = None
@@ -758,10 +815,19 @@ def main():
                                "microbench_launch_ms": r["ms"], "microbench_frac": r["frac"],
                                "rocprofv3_in_step_us": r.get("in_step_us_rocprofv3"),
                                "rocprofv3_source": r.get("in_step_rocprofv3_source")}
+            if r["bound"] == "hbm" and "gdn_chunk" in dom:
+                # SURVEY.md 8(d)'s own byte count for the GDN call -- 24,672 B per token + 4 MiB of fp32 state read + written --
+                # beside the count above, which takes the state in the dtype the cache actually holds (bf16: 2 MiB)
+                survey_bytes = 24672 * T + 4 * 1024 * 1024
+                out["roofline"]["survey_bytes_per_launch"] = survey_bytes
+                out["roofline"]["frac_survey_bytes"] = survey_bytes / (dur_ms * 1e-3) / 1e9 / r["peak"]
             out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                               for k, v in kernels.items()}
             out["hot_path_ms_per_step"] = sum(call_ms(v) * v["launches_per_step"] for v in prefill_kernels.values())
             out["hot_path_ms_per_step_microbench"] = sum(v["ms"] * v["launches_per_step"] for v in prefill_kernels.values())
+            # what is NOT the path's kernels: library GEMMs at M = 256 (stock hipBLASLt, out of SURVEY.md section 8's scope) + torch glue
+            out["gemm_ms_per_step"] = out["ms_per_step"] - out["hot_path_ms_per_step"]
+            out["in_scope_share_of_step"] = out["hot_path_ms_per_step"] / out["ms_per_step"]
             out["hot_path_ms_per_decode_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
                                                       for k, v in decode_kernels.items() if not k.startswith("decode linear"))
             out["decode_linear_ms_per_token"] = sum(call_ms(v) * v["launches_per_decode_token"]
@@ -773,6 +839,8 @@ def main():
         if cfg3 is not None:
             out["cfg3_512k_prefill"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg3.items()}
         if dist_info is not None:
+            if sp is not None:
+                dist_info["sp"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sp.items()}
             out["dist"] = dist_info
         if cfg1 is not None:
             out["cfg1_4k_prefill_decode"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cfg1.items()}

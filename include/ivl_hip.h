@@ -156,6 +156,8 @@ IVL_API int ivl_short_conv_fwd(const void* x, const void* weight, const void* st
  * y = rmsnorm(x) * weight * gate * sigmoid(gate), rows of N == 256, statistics in fp32.
  * Replaces fla.modules.FusedRMSNormGated.forward (call site std:1338;
  *   fla:modules/fused_norm_gate.py:27-95).  x, gate, y bf16 [rows,N]; weight bf16 [N].
+ * gate == NULL: y = rmsnorm(x) * weight with fla's rounding (x * rstd * w in fp32, one rounding at the store) =
+ *   fla.modules.RMSNorm.forward (fla:modules/layernorm.py:103-143), the mixer's output norm when use_gate=False (std:1213).
  * ------------------------------------------------------------------------------------------- */
 IVL_API int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
                                int rows, int N, float eps, void* stream);
@@ -325,7 +327,8 @@ IVL_API int ivl_linear_swiglu_small_m_fwd(const void* x, const void* w_gate_up, 
 /* (Residual add +) RMSNorm in the prologue of the decode step's projection: ivl_add_rmsnorm_fwd followed by
  * ivl_linear_small_m_fwd (glu == 0) or ivl_linear_swiglu_small_m_fwd (glu != 0, N = I), bit for bit, in ONE launch --
  * the decoder layer's input_layernorm -> q|k|v / GDN in-projection, post_attention_layernorm -> gate|up, and the final
- * norm -> lm_head (std:1350-1429, 1573, 2091-2092) at q_len == 1: 73 one-row norm launches per token disappear.
+ * norm -> lm_head (std:1350-1429, 1573, 2091-2092) at q_len == 1.  (The package routes the 72 per-layer norms of a decode token through
+ * it; the final norm in front of lm_head stays a launch of its own.)
  *   h = bf16(x + residual) (residual NULL: h = x; else written to h_out [M,K]);  xn = bf16(norm_weight * bf16(h * rstd(h)));
  *   y = linear(xn).  x, residual, h_out bf16 [M,K]; norm_weight bf16 [K]; 512 <= K <= 4096; the rest as the two entry points above. */
 IVL_API int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, const void* norm_weight, float eps, void* h_out,

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void short_conv_kernel(
 // ------------------------------------------------------------------------------------------------
 // gated RMSNorm over rows of 256: half a wavefront (32 lanes x 8 bf16) per row.
 // ------------------------------------------------------------------------------------------------
+// GATED = false: the plain RMSNorm of fla (fla:modules/layernorm.py: y = x * rstd * w in fp32, rounded ONCE at the store) -- the
+// output norm of a GatedDeltaNet built with use_gate=False (std:1213).
+template <bool GATED>
 __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate, const bf16_t* __restrict__ weight,
     bf16_t* __restrict__ y, int rows, float eps) {
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
   const float wf[8] = {bflo(wv.x), bfhi(wv.x), bflo(wv.y), bfhi(wv.y), bflo(wv.z), bfhi(wv.z), bflo(wv.w), bfhi(wv.w)};
   for (long long r = row0; r < rows; r += stride) {
     u32x4 xv = *(const u32x4*)(x + r * 256 + lane32 * 8);
-    u32x4 gv = *(const u32x4*)(gate + r * 256 + lane32 * 8);
+    u32x4 gv = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (GATED) gv = *(const u32x4*)(gate + r * 256 + lane32 * 8);
     float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
     float gf[8] = {bflo(gv.x), bfhi(gv.x), bflo(gv.y), bfhi(gv.y), bflo(gv.z), bfhi(gv.z), bflo(gv.w), bfhi(gv.w)};
     float ss = 0.f;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
     float o8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o8[i] = xf[i] * rstd * wf[i] * gf[i] * sigmoidf_(gf[i]);
+    for (int i = 0; i < 8; ++i) o8[i] = GATED ? xf[i] * rstd * wf[i] * gf[i] * sigmoidf_(gf[i]) : xf[i] * rstd * wf[i];
     u32x4 ov;
     ov.x = pack2bf(o8[0], o8[1]); ov.y = pack2bf(o8[2], o8[3]);
     ov.z = pack2bf(o8[4], o8[5]); ov.w = pack2bf(o8[6], o8[7]);
@@ -315,11 +319,15 @@ extern "C" int ivl_short_conv_fwd(const void* x, const void* weight, const void*
 
 extern "C" int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
                                           int rows, int N, float eps, void* stream) {
-  IVL_REQUIRE(x && gate && weight && y, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_fwd: NULL pointer");
+  IVL_REQUIRE(x && weight && y, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_fwd: NULL pointer");
   IVL_REQUIRE(rows > 0, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_fwd: rows=%d", rows);
   IVL_REQUIRE(N == 256, IVL_ERR_UNSUPPORTED, "ivl_rmsnorm_swish_gate_fwd: N=%d unsupported (built for head_v_dim 256)", N);
-  hipLaunchKernelGGL(rmsnorm_gate_kernel, dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)weight, (bf16_t*)y, rows, eps);
+  if (gate != nullptr)
+    hipLaunchKernelGGL(rmsnorm_gate_kernel<true>, dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)weight, (bf16_t*)y, rows, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_gate_kernel<false>, dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)weight, (bf16_t*)y, rows, eps);
   return check_launch("ivl_rmsnorm_swish_gate_fwd");
 }
 

@@ -40,9 +40,10 @@ constexpr int LSM_NORM_KMAX = 4096;
 
 // N = number of OUTPUT columns (GLU: I; the weight then has 2N rows)
 // NIT: 16-byte pieces of a row per thread in the norm prologue (1: K <= 2048 -- the hidden size of the model; 2: K <= 4096);
-// the prologue's registers are live while the first weight batch is in flight, and 218 VGPRs meant 2 workgroups per CU
+// the prologue's registers are live while the first weight batch is in flight, and 218 VGPRs meant 2 workgroups per CU: the M = 1
+// instances (the decode token) are capped at 168 (three workgroups per CU); M >= 2 would spill there and keeps the default
 template <int RPW, int M, bool GLU, bool NORM, int NIT = 2>
-__global__ __launch_bounds__(256, NORM ? 3 : 1) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256, (NORM && M == 1) ? 3 : 1) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
                                                             int N, int K, NormArgs na) {
   constexpr int NR = GLU ? 2 * RPW : RPW;          // weight rows per wave
@@ -241,5 +242,5 @@ extern "C" int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, 
               "ivl_norm_linear_small_m_fwd: K=%d (the normalised rows are staged in LDS by the whole workgroup: 512 <= K <= %d)", K, LSM_NORM_KMAX);
   NormArgs na;
   na.residual = (const bf16_t*)residual; na.weight = (const bf16_t*)norm_weight; na.h_out = (bf16_t*)h_out; na.eps = eps;
-  return lsm_dispatch<true>(x, w, bias, y, M, glu ? N : N, K, glu != 0, na, stream, "ivl_norm_linear_small_m_fwd");
+  return lsm_dispatch<true>(x, w, bias, y, M, N, K, glu != 0, na, stream, "ivl_norm_linear_small_m_fwd");
 }

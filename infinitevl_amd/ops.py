@@ -79,8 +79,11 @@ def get_workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch
         if ws is not None and _GRAPH_PINNED.get(key):
             _RETIRED.append(ws)
             _GRAPH_PINNED[key] = False
-        # geometric growth bounds the number of retired (graph-pinned) buffers of a run whose calls keep growing
-        grown = 2 * ws.numel() if ws is not None else 0
+        # geometric growth bounds the number of retired (graph-pinned) buffers of a run whose calls keep growing; above 256 MiB
+        # it is +25 % (a retired multi-GB buffer stays alive beside its successor: doubling there can exhaust the device)
+        grown = 0
+        if ws is not None:
+            grown = 2 * ws.numel() if ws.numel() < (256 << 20) else ws.numel() + ws.numel() // 4
         ws = torch.empty(max(int(nbytes), grown, 1 << 20), dtype=torch.uint8, device=device)
         _WORKSPACES[key] = ws
     if capturing:
@@ -482,8 +485,10 @@ class FusedRMSNormGated(nn.Module):
 
 class RMSNorm(nn.Module):
     """y = rmsnorm(x) * weight over the last dim (fla.modules.RMSNorm; the reference's `o_norm` when
-    `use_gate=False`, std:1213 / std:1341).  Same constructor and parameter names as fla's; the arithmetic is the
-    residual-free form of ivl_add_rmsnorm_fwd (fp32 statistics, bf16 in / out)."""
+    `use_gate=False`, std:1213 / std:1341).  Same constructor and parameter names as fla's.  At the width InfiniteVL uses it
+    for (head_v_dim = 256) the arithmetic is fla's own (fla:modules/layernorm.py: x * rstd * w in fp32, rounded ONCE):
+    ivl_rmsnorm_swish_gate_fwd without a gate.  Other widths go through ivl_add_rmsnorm_fwd, which rounds x * rstd to bf16
+    before the weight (the Qwen2RMSNorm form of the decoder layers): up to 1 bf16 ulp from fla there."""
 
     def __init__(self, hidden_size: int, elementwise_affine: bool = True, bias: bool = False, eps: float = 1e-5,
                  device=None, dtype=None):
@@ -503,6 +508,13 @@ class RMSNorm(nn.Module):
         if residual is not None or prenorm:
             raise NotImplementedError("residual/prenorm are not used by InfiniteVL (std:1341)")
         w = self.weight if self.weight is not None else torch.ones(self.hidden_size, dtype=x.dtype, device=x.device)
+        if self.hidden_size == 256 and x.dtype == torch.bfloat16:
+            _need_gpu(x)
+            xc = x.contiguous()
+            y = torch.empty_like(xc)
+            _lib.check(_lib.load().ivl_rmsnorm_swish_gate_fwd(_p(xc), None, _p(w.to(torch.bfloat16).contiguous()), _p(y),
+                                                              xc.numel() // 256, 256, float(self.eps), _stream(xc)))
+            return y
         y, _ = add_rmsnorm(x, None, w, self.eps)
         return y
 

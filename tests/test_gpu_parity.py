@@ -1226,6 +1226,27 @@ def test_gdn_module_without_output_gate():
     assert o.shape == x.shape and torch.equal(o, want)
 
 
+def test_plain_rmsnorm_has_flas_single_rounding():
+    """ops.RMSNorm at head_v_dim = 256 (the mixer's output norm when use_gate=False): fla's arithmetic -- x * rstd * w in fp32,
+    rounded to bf16 once (fla:modules/layernorm.py:128-143) -- bit for bit against the same expression in torch fp32; the
+    Qwen2RMSNorm form (x * rstd rounded first) differs from it in a few per cent of the elements."""
+    from infinitevl_amd import ops
+    g_ = torch.Generator(device=DEV).manual_seed(5)
+    x = bf(torch.randn(3, 70, 4, 256, device=DEV, generator=g_) * 3.0)
+    m = ops.RMSNorm(256, eps=1e-6, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        m.weight.copy_(bf(torch.randn(256, device=DEV, generator=g_)))
+        y = m(x)
+    xf, wf = x.float(), m.weight.float()
+    rstd = 1.0 / torch.sqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    want = bf(xf * rstd * wf)
+    mism = (y != want).float().mean().item()
+    assert rms_rel(y, (xf * rstd * wf)) < 3e-3
+    assert mism < 2e-3, mism                      # (the kernel's statistic sums in another order than torch's mean: rare 1-ulp flips)
+    qwen = bf(wf * bf(xf * rstd).float())
+    assert (qwen != want).float().mean().item() > 5 * max(mism, 1e-3)
+
+
 def test_cache_error_behaviour_on_gpu():
     from infinitevl_amd.cache import StaticCachePrealloc
     stack, hc, _, _ = _small_stack(window=96)
@@ -1500,7 +1521,7 @@ def test_bench_two_ranks_reports_what_the_collective_ran_on():
         env.pop(k, None)
     r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--layers", "4", "--context", "8192", "--decode-steps", "2", "--no-cpu-baseline", "--no-cfg1", "--no-cfg3",
-                        "--no-fp8", "--no-kernel-timing"], capture_output=True, text=True, timeout=900, env=env)
+                        "--no-fp8", "--no-kernel-timing", "--sp-tokens", "1024"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = _json.loads(line)
@@ -1510,6 +1531,13 @@ def test_bench_two_ranks_reports_what_the_collective_ran_on():
     assert [x["rank"] for x in d["devices"]] == [0, 1] and all(x["pci_bus_id"] for x in d["devices"])
     assert d["gathered_logits_shape"] == [2, 151936] and d["allgather_ms"] > 0 and d["logits_rows_differ_across_ranks"]
     assert d["distinct_devices"] == 1          # two gloo ranks stacked on one GPU; RCCL runs assert == world
+    # the sequence-parallel prefill leg rides on the same process group: one 2 x 1024-token sequence, the last
+    # rank's last-token logits equal its own single-rank run of the same two calls bit for bit; under gloo the hand-off is
+    # host-staged and the record says so
+    sp = d["sp"]
+    assert sp["tokens"] == 2048 and sp["backend"] == "gloo" and sp["device_p2p"] is False and "host-staged" in sp["transport"]
+    assert sp["last_token_logits_equal_single_rank_run"] is True and sp["max_abs_diff"] == 0.0 and sp["logits_finite"]
+    assert sp["ms"] > 0 and sp["tok_s"] > 0 and sp["single_rank_ms_same_calls"] > 0
     assert out["logits_finite"] and out["value"] > 0
 
 
