@@ -278,7 +278,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
     unsigned char* smem, const int ci, const int bh,
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const float* __restrict__ g,
     const bf16_t* __restrict__ beta, const PrepFused& pf, unsigned char* __restrict__ ws, int T, int H, int t_seg0, int nt_seg, int l2norm,
-    unsigned int* done, unsigned int* kread, const ScanSync* sy) {
+    unsigned int* done, unsigned int* kread, const ScanSync* sy, const int tid_off = 0) {
   static_assert(ROLE == 0 || FUSED, "the split pre-pass exists for the fused front end only");
   constexpr bool KONLY = ROLE == 1, DO_K = ROLE != 2, DO_Q = ROLE != 1;
   using R = Rec<F8>;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void gdn_chunk_prepare_body(
 #endif
   // (the thread index passes through an empty asm statement: inside the persistent loop of the long-call form nothing derived
   // from it is hoisted out of the body and kept alive across it -- the body stays at its straight-line register count)
-  int tid_opaque = threadIdx.x;
+  int tid_opaque = (int)threadIdx.x - tid_off;          // (tid_off: the long-call form runs two bodies per 1024-thread workgroup)
   if constexpr (LOOPED) asm volatile("" : "+v"(tid_opaque));
   const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -2012,8 +2012,11 @@ static_assert(G_SYNC_BYTES >= 4 * (SYNC_ERR_WORD + 4), "sync area layout");
 // launch gets the scan's 156 KB of LDS, i.e. one CU: the host sizes nprep = resident workgroups - 8 BH (at least 8 BH).
 // A mode is a template instance of its own: the step-shape kernel (MODE 1) carries none of the long-call code.
 // MODE: 0 = small grid, whole pre-pass per chunk; 1 = small grid, split pre-pass; 2 = long call
+constexpr int LONG_THREADS = 1024;                 // MODE 2: a pre-pass workgroup = TWO 512-thread bodies (two chunk-head pairs at once)
+constexpr int P_BODY_STRIDE = (P_BYTES + 1023) / 1024 * 1024;      // LDS of the second body starts here
+static_assert(2 * P_BODY_STRIDE <= scan_lds_bytes(2, false) && 2 * P_BODY_STRIDE <= 160 * 1024, "two pre-pass bodies fit the launch's LDS");
 template <bool F8, int MODE>
-__global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
+__global__ __launch_bounds__(MODE == 2 ? LONG_THREADS : SINGLE_THREADS) void gdn_chunk_single_kernel(
     PrepFused pf, unsigned char* __restrict__ ws, bf16_t* __restrict__ o, ScanV sv, const void* h0, int h0_dtype, void* ht,
     int ht_dtype, int T, int H, int BH, int t_seg0, int nt_seg, int nprep, float scale, ScanSync sy) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -2021,8 +2024,14 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
   const int nside = nt_seg * BH;                       // (chunk, head) pairs of the segment; nprep = pre-pass workgroups of the launch
   int id = (int)blockIdx.x;
   if (id < nprep) {
-    if (threadIdx.x >= 512) return;
     if constexpr (LONG) {
+      // Two bodies per workgroup, threads [0, 512) and [512, 1024), each with its own 70 KB of LDS and its own (chunk, head)
+      // pair: the launch's LDS size (the scan's 156 KB) admits one workgroup per CU, and ONE body per CU is latency-bound
+      // (measured: the scan waited 1.2k of its 2.9k cycles per chunk for the records; two bodies per CU are what the two-launch
+      // pre-pass runs at).  Both halves execute the same barrier sequence (same code, equal trip counts: the host keeps the
+      // pair count even), so the bodies' workgroup barriers simply span both.
+      const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 9);       // (wave-uniform: kept in an SGPR)
+      unsigned char* smem_body = smem + half * P_BODY_STRIDE;
       // the front-end arguments are re-read from the kernel-argument segment in every round (scalar loads through a pointer the
       // compiler cannot see through): held in SGPRs across the whole body they exceed the scalar register file
       static_assert(__builtin_offsetof(PrepFused, proj) == 0, "pf is the first kernel argument");
@@ -2032,7 +2041,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
 #else
       const unsigned int* kp = (const unsigned int*)&pf;
 #endif
-      for (int w = id; w < nside; w += nprep) {        // (the publish at the end of the body is a workgroup barrier: LDS is free again)
+      for (int w = 2 * id + half; w < nside; w += 2 * nprep) {   // (the publish at the end of the body is a workgroup barrier: LDS is free again)
         asm volatile("" : "+s"(kp));
         PrepFused pfl;
         {
@@ -2043,10 +2052,11 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
           __builtin_memcpy(&pfl, words, sizeof(PrepFused));
         }
         const int ci = w / BH, bh = w % BH;
-        gdn_chunk_prepare_body<F8, true, true, 0, true>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pfl, ws, T, H, t_seg0, nt_seg, 1,
-                                                  sy.flags + bh * SYNC_HEAD_WORDS + ci, nullptr, &sy);
+        gdn_chunk_prepare_body<F8, true, true, 0, true>(smem_body, ci, bh, nullptr, nullptr, nullptr, nullptr, pfl, ws, T, H, t_seg0, nt_seg, 1,
+                                                  sy.flags + bh * SYNC_HEAD_WORDS + ci, nullptr, &sy, half * 512);
       }
     } else {
+      if (threadIdx.x >= 512) return;
       bool qside = false;
       if constexpr (SPLIT) {                           // ids: q sides of chunk 0 | k sides | q sides of chunks 1..
         if (id < BH) { qside = true; }
@@ -2068,6 +2078,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void gdn_chunk_single_kernel(
         gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh, &sy);
     }
   } else {
+    if (LONG && threadIdx.x >= SINGLE_THREADS) return;     // (the long-call launch has 1024-thread workgroups: a scan workgroup uses 12 waves)
     id -= nprep;
     gdn_chunk_scan_body<2, F8, true, LONG ? 2 : 1>(smem, id % BH, id / BH, ws, o, sv, h0, h0_dtype, ht, ht_dtype, T, H, t_seg0, nt_seg,
                                                    scale, sy);
@@ -2112,7 +2123,8 @@ static int resident_blocks(bool f8) {
 template <bool F8, int MODE>
 static int single_occupancy(int lds, int cus) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gdn_chunk_single_kernel<F8, MODE>, SINGLE_THREADS, (size_t)lds) != hipSuccess) nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gdn_chunk_single_kernel<F8, MODE>, MODE == 2 ? LONG_THREADS : SINGLE_THREADS,
+                                                   (size_t)lds) != hipSuccess) nb = 0;
   return nb * cus;
 }
 // dynamic-LDS opt-in, occupancy and the host status word, once per device (hipFuncSetAttribute acts on the current device)
@@ -2197,6 +2209,9 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   const int segc = seg_chunks(NT);
   float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * Rec<false>::STRIDE) : nullptr;
   int ncw = B * H * 4 <= 128 ? 2 : 4;          // 32-column workgroups while 64-column ones would leave half the CUs idle
+#ifdef IVL_AB_NCW
+  ncw = IVL_AB_NCW;                            // (developer A/B builds only)
+#endif
 #ifdef IVL_TRACE
   if (g_scan_ncw) ncw = g_scan_ncw;
 #endif
@@ -2214,7 +2229,8 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   const bool can_sync = pf != nullptr && sync != nullptr && ncw == 2 && BH <= SYNC_MAX_HEADS;
   bool single = can_sync && NT <= 63 && NT * BH + (16 / 2) * BH <= resident;
   // long calls: one launch per segment, persistent pre-pass workgroups beside the scan workgroups -- at least as many of them
-  bool overlap = can_sync && !single && 2 * 8 * BH <= resident;
+  // (an even number of (chunk, head) pairs per segment: a pre-pass workgroup runs two bodies side by side)
+  bool overlap = can_sync && !single && 2 * 8 * BH <= resident && (BH % 2 == 0 || (segc % 2 == 0 && NT % 2 == 0));
 #ifdef IVL_TRACE
   single = single && g_gdn_single != 0;
   overlap = overlap && g_gdn_single != 0 && g_gdn_single != 3;
@@ -2249,9 +2265,8 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
       void* hout = last ? ht : (void*)carry;
       const int hout_dt = last ? ht_dtype : IVL_F32;
       int nprep = resident - 8 * BH;                               // persistent pre-pass workgroups: what the chip holds beside the scan
-      if (nprep > nseg * BH) nprep = nseg * BH;
-      if ((BH & 7) == 0) nprep -= nprep % BH;                      // whole rounds of heads: a head's records stay on its die (id % 8)
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nprep + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
+      if (nprep > nseg * BH / 2) nprep = nseg * BH / 2;            // (two chunk-head pairs per workgroup and round)
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nprep + 8 * BH), dim3(LONG_THREADS), lds1, st, *pf, wsb,
                          (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, nprep, scale, sy);
       int rc = check_launch("ivl_gdn_chunk_fused_fwd(overlapped launch)");
       if (rc != IVL_OK) return rc;
