@@ -151,6 +151,10 @@ IVL_API int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, c
  * ------------------------------------------------------------------------------------------- */
 IVL_API int ivl_short_conv_fwd(const void* x, const void* weight, const void* state_in, void* y, void* state_out,
                        int B, int T, int D, int W, int apply_silu, void* stream);
+/* The same with fla's `bias=True` option (fla:modules/convolution.py:128-160; InfiniteVL uses conv_bias = False): bias bf16 [D]
+ * (NULL = none); y = act(bias + sum_j w[.,j] x[t - W + 1 + j]), the accumulator starting from the bias as in causal_conv1d. */
+IVL_API int ivl_short_conv_bias_fwd(const void* x, const void* weight, const void* bias, const void* state_in, void* y, void* state_out,
+                            int B, int T, int D, int W, int apply_silu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = rmsnorm(x) * weight * gate * sigmoid(gate), rows of N == 256, statistics in fp32.
@@ -161,6 +165,11 @@ IVL_API int ivl_short_conv_fwd(const void* x, const void* weight, const void* st
  * ------------------------------------------------------------------------------------------- */
 IVL_API int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const void* weight, void* y,
                                int rows, int N, float eps, void* stream);
+/* The same with fla's residual= / prenorm= / residual_in_fp32= options (fla:modules/fused_norm_gate.py:54-60, 98-155; not used by
+ * InfiniteVL): the row is x + residual in fp32 (residual [rows,N] IVL_BF16 or IVL_F32; NULL = none), written to residual_out
+ * ([rows,N] IVL_BF16 or IVL_F32; NULL = not wanted); statistics and output are those of the unrounded fp32 row. */
+IVL_API int ivl_rmsnorm_swish_gate_res_fwd(const void* x, const void* gate, const void* weight, const void* residual, int residual_dtype,
+                                   void* residual_out, int residual_out_dtype, void* y, int rows, int N, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multimodal rotary embedding applied in place to q [B,T,Hq,d] and k [B,T,Hkv,d] (bf16,

@@ -33,8 +33,9 @@ int check_launch(const char* what) {
 constexpr int CONV_W = 4;
 constexpr int CONV_TCH = 8;
 
+// bias (fla's ShortConvolution(bias=True), not used by InfiniteVL): the accumulator starts from it, as in causal_conv1d.
 __global__ __launch_bounds__(256) void short_conv_kernel(
-    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* state_in,
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, const bf16_t* state_in,
     bf16_t* __restrict__ y, bf16_t* state_out, int B, int T, int D, int apply_silu) {
   const int DG = D / 8;
   const int NCH = (T + CONV_TCH - 1) / CONV_TCH;
@@ -101,6 +102,8 @@ __global__ __launch_bounds__(256) void short_conv_kernel(
         win[k][4] = bflo(v.z); win[k][5] = bfhi(v.z); win[k][6] = bflo(v.w); win[k][7] = bfhi(v.w);
       }
     }
+    float bf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) unpack8(*(const u32x4*)(bias + d0), bf);
     const int tend = min(t0 + CONV_TCH, T);
     for (int t = t0; t < tend; ++t) {
       u32x4 v = *(const u32x4*)(xb + (size_t)t * D);
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void short_conv_kernel(
       float out[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        float a = wf[c][0] * win[0][c];
+        float a = bias != nullptr ? fmaf(wf[c][0], win[0][c], bf[c]) : wf[c][0] * win[0][c];
         a = fmaf(wf[c][1], win[1][c], a);
         a = fmaf(wf[c][2], win[2][c], a);
         a = fmaf(wf[c][3], cur[c], a);
@@ -161,10 +164,17 @@ __global__ __launch_bounds__(256) void short_conv_kernel(
 // ------------------------------------------------------------------------------------------------
 // GATED = false: the plain RMSNorm of fla (fla:modules/layernorm.py: y = x * rstd * w in fp32, rounded ONCE at the store) -- the
 // output norm of a GatedDeltaNet built with use_gate=False (std:1213).
-template <bool GATED>
+// RES (fla's residual= / prenorm= / residual_in_fp32= options, fla:modules/fused_norm_gate.py:54-60; not used by InfiniteVL):
+// the row is x + residual in fp32 (residual: bf16 or fp32), stored to residual_out (bf16 or fp32) when wanted, and the
+// statistics and the output are those of the UNROUNDED fp32 row, as in the reference kernel.
+struct NormRes {
+  const void* residual; int residual_dtype;      // NULL: none
+  void* residual_out; int residual_out_dtype;    // NULL: not stored
+};
+template <bool GATED, bool RES = false>
 __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate, const bf16_t* __restrict__ weight,
-    bf16_t* __restrict__ y, int rows, float eps) {
+    bf16_t* __restrict__ y, int rows, float eps, NormRes nr = NormRes{nullptr, 0, nullptr, 0}) {
   const int lane32 = threadIdx.x & 31;
   const long long row0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 5;
@@ -176,6 +186,28 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_kernel(
     if constexpr (GATED) gv = *(const u32x4*)(gate + r * 256 + lane32 * 8);
     float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
     float gf[8] = {bflo(gv.x), bfhi(gv.x), bflo(gv.y), bfhi(gv.y), bflo(gv.z), bfhi(gv.z), bflo(gv.w), bfhi(gv.w)};
+    if constexpr (RES) {
+      const size_t e0 = (size_t)r * 256 + lane32 * 8;
+      if (nr.residual != nullptr) {
+        float rf[8];
+        if (nr.residual_dtype == IVL_F32) {
+          const f32x4 a = *(const f32x4*)((const float*)nr.residual + e0), b = *(const f32x4*)((const float*)nr.residual + e0 + 4);
+          rf[0] = a[0]; rf[1] = a[1]; rf[2] = a[2]; rf[3] = a[3]; rf[4] = b[0]; rf[5] = b[1]; rf[6] = b[2]; rf[7] = b[3];
+        } else {
+          unpack8(*(const u32x4*)((const bf16_t*)nr.residual + e0), rf);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[i] += rf[i];
+      }
+      if (nr.residual_out != nullptr) {
+        if (nr.residual_out_dtype == IVL_F32) {
+          *(f32x4*)((float*)nr.residual_out + e0) = f32x4{xf[0], xf[1], xf[2], xf[3]};
+          *(f32x4*)((float*)nr.residual_out + e0 + 4) = f32x4{xf[4], xf[5], xf[6], xf[7]};
+        } else {
+          *(u32x4*)((bf16_t*)nr.residual_out + e0) = pack8(xf);
+        }
+      }
+    }
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss = fmaf(xf[i], xf[i], ss);
@@ -312,7 +344,7 @@ extern "C" int ivl_short_conv_fwd(const void* x, const void* weight, const void*
   IVL_REQUIRE(D % 8 == 0, IVL_ERR_UNSUPPORTED, "ivl_short_conv_fwd: D=%d must be a multiple of 8", D);
   const long long items = (long long)B * ((T + CONV_TCH - 1) / CONV_TCH) * (D / 8);
   hipLaunchKernelGGL(short_conv_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)state_in, (bf16_t*)y, (bf16_t*)state_out,
+                     (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)nullptr, (const bf16_t*)state_in, (bf16_t*)y, (bf16_t*)state_out,
                      B, T, D, apply_silu);
   return check_launch("ivl_short_conv_fwd");
 }
@@ -329,6 +361,33 @@ extern "C" int ivl_rmsnorm_swish_gate_fwd(const void* x, const void* gate, const
     hipLaunchKernelGGL(rmsnorm_gate_kernel<false>, dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)weight, (bf16_t*)y, rows, eps);
   return check_launch("ivl_rmsnorm_swish_gate_fwd");
+}
+
+extern "C" int ivl_rmsnorm_swish_gate_res_fwd(const void* x, const void* gate, const void* weight, const void* residual, int residual_dtype,
+                                              void* residual_out, int residual_out_dtype, void* y, int rows, int N, float eps, void* stream) {
+  IVL_REQUIRE(x && gate && weight && y, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_res_fwd: NULL pointer");
+  IVL_REQUIRE(rows > 0, IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_res_fwd: rows=%d", rows);
+  IVL_REQUIRE(N == 256, IVL_ERR_UNSUPPORTED, "ivl_rmsnorm_swish_gate_res_fwd: N=%d unsupported (built for head_v_dim 256)", N);
+  IVL_REQUIRE((residual == nullptr || residual_dtype == IVL_F32 || residual_dtype == IVL_BF16) &&
+              (residual_out == nullptr || residual_out_dtype == IVL_F32 || residual_out_dtype == IVL_BF16),
+              IVL_ERR_INVALID_ARG, "ivl_rmsnorm_swish_gate_res_fwd: residual dtype must be IVL_F32 or IVL_BF16");
+  hipLaunchKernelGGL((rmsnorm_gate_kernel<true, true>), dim3(grid_for((long long)rows * 32)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)weight, (bf16_t*)y, rows, eps,
+                     NormRes{residual, residual_dtype, residual_out, residual_out_dtype});
+  return check_launch("ivl_rmsnorm_swish_gate_res_fwd");
+}
+
+extern "C" int ivl_short_conv_bias_fwd(const void* x, const void* weight, const void* bias, const void* state_in, void* y, void* state_out,
+                                       int B, int T, int D, int W, int apply_silu, void* stream) {
+  IVL_REQUIRE(x && weight && y, IVL_ERR_INVALID_ARG, "ivl_short_conv_bias_fwd: NULL x/weight/y");
+  IVL_REQUIRE(B > 0 && T > 0 && D > 0, IVL_ERR_INVALID_ARG, "ivl_short_conv_bias_fwd: B,T,D must be positive (got %d,%d,%d)", B, T, D);
+  IVL_REQUIRE(W == CONV_W, IVL_ERR_UNSUPPORTED, "ivl_short_conv_bias_fwd: kernel size %d unsupported (built for 4)", W);
+  IVL_REQUIRE(D % 8 == 0, IVL_ERR_UNSUPPORTED, "ivl_short_conv_bias_fwd: D=%d must be a multiple of 8", D);
+  const long long items = (long long)B * ((T + CONV_TCH - 1) / CONV_TCH) * (D / 8);
+  hipLaunchKernelGGL(short_conv_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)bias, (const bf16_t*)state_in, (bf16_t*)y, (bf16_t*)state_out,
+                     B, T, D, apply_silu);
+  return check_launch("ivl_short_conv_bias_fwd");
 }
 
 extern "C" int ivl_gdn_gate_fwd(const void* a, const void* b, const float* A_log, const float* dt_bias,

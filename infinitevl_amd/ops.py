@@ -403,20 +403,23 @@ class ShortConvolution(nn.Module):
     def __init__(self, hidden_size: int, kernel_size: int, bias: bool = False, activation: Optional[str] = "silu",
                  use_fast_conv1d: Optional[bool] = True, device=None, dtype=None, **_unused):
         super().__init__()
-        if bias:
-            raise NotImplementedError("InfiniteVL uses conv_bias=False (configuration_infinitevl.py)")
         if activation is not None:
             assert activation in ["silu", "swish"], f"Activation `{activation}` not supported yet."
         self.hidden_size = hidden_size
         self.kernel_size = (kernel_size,)
         self.activation = activation
         self.weight = nn.Parameter(torch.empty(hidden_size, 1, kernel_size, device=device, dtype=dtype))
-        self.register_parameter("bias", None)
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:                                                         # nn.Conv1d's parameter and initialisation (convolution.py:128-160)
+            self.bias = nn.Parameter(torch.empty(hidden_size, device=device, dtype=dtype))
+            bound = 1.0 / (kernel_size ** 0.5)                           # fan_in = (in_channels / groups) * kernel_size
+            nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter("bias", None)
 
     def extra_repr(self) -> str:
         return (f"{self.hidden_size}, {self.hidden_size}, kernel_size={self.kernel_size}, groups={self.hidden_size}, "
-                f"bias=False, activation={self.activation}")
+                f"bias={self.bias is not None}, activation={self.activation}")
 
     @property
     def state_size(self) -> int:                                         # convolution.py:295-297
@@ -444,6 +447,11 @@ class ShortConvolution(nn.Module):
         w = self.weight
         if w.dtype != torch.bfloat16:
             w = w.to(torch.bfloat16)
+        if self.bias is not None:
+            _lib.check(_lib.load().ivl_short_conv_bias_fwd(
+                _p(x), _p(w.contiguous()), _p(self.bias.to(torch.bfloat16).contiguous()), _p(state_in), _p(y), _p(cache), B, T, D, W,
+                int(self.activation is not None), _stream(x)))
+            return y, cache
         _lib.check(_lib.load().ivl_short_conv_fwd(
             _p(x), _p(w.contiguous()), _p(state_in), _p(y), _p(cache), B, T, D, W,
             int(self.activation is not None), _stream(x)))
@@ -462,22 +470,37 @@ class FusedRMSNormGated(nn.Module):
         super().__init__()
         if activation not in ("swish", "silu"):
             raise ValueError(f"Unsupported activation: {activation}")
-        if not elementwise_affine:
-            raise NotImplementedError("InfiniteVL's o_norm is affine")
-        self.hidden_size, self.eps, self.activation = hidden_size, eps, activation
-        self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+        self.hidden_size, self.elementwise_affine, self.eps, self.activation = hidden_size, elementwise_affine, eps, activation
+        if elementwise_affine:
+            self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+        else:
+            self.register_parameter("weight", None)
         self.register_parameter("bias", None)
 
     def forward(self, x: torch.Tensor, g: torch.Tensor, residual=None, prenorm=False, residual_in_fp32=False):
-        if residual is not None or prenorm:
-            raise NotImplementedError("residual/prenorm are not used by InfiniteVL (std:1338)")
-        _need_gpu(x, g)
+        _need_gpu(x, g, residual)
         if x.dtype != torch.bfloat16:
             raise ValueError(f"FusedRMSNormGated kernel is built for bf16, got {x.dtype}")
         N = x.shape[-1]
         x, g = x.contiguous(), g.contiguous()
         y = torch.empty_like(x)
-        w = self.weight if self.weight.dtype == torch.bfloat16 else self.weight.to(torch.bfloat16)
+        if self.weight is None:                                         # elementwise_affine=False: x * rstd * 1
+            w = torch.ones(N, dtype=torch.bfloat16, device=x.device)
+        else:
+            w = self.weight if self.weight.dtype == torch.bfloat16 else self.weight.to(torch.bfloat16)
+        if residual is not None or prenorm or residual_in_fp32:
+            # fla's residual path (fused_norm_gate.py:98-155, 688-721): row = x + residual in fp32; residual_out in the residual's
+            # dtype (fp32 when only residual_in_fp32 is set); returned when prenorm
+            if residual is not None:
+                if residual.dtype not in _DT_CODE or tuple(residual.shape) != tuple(x.shape):
+                    raise ValueError("residual must be a bf16 / fp32 tensor of x's shape")
+                residual = residual.contiguous()
+            res_dt = residual.dtype if residual is not None else (torch.float32 if residual_in_fp32 else None)
+            res_out = torch.empty(x.shape, dtype=res_dt, device=x.device) if res_dt is not None and (residual is not None or res_dt != x.dtype) else None
+            _lib.check(_lib.load().ivl_rmsnorm_swish_gate_res_fwd(
+                _p(x), _p(g), _p(w.contiguous()), _p(residual), _DT_CODE[residual.dtype] if residual is not None else IVL_BF16,
+                _p(res_out), _DT_CODE[res_out.dtype] if res_out is not None else IVL_BF16, _p(y), x.numel() // N, N, float(self.eps), _stream(x)))
+            return y if not prenorm else (y, res_out if res_out is not None else x)
         _lib.check(_lib.load().ivl_rmsnorm_swish_gate_fwd(_p(x), _p(g), _p(w.contiguous()), _p(y),
                                                           x.numel() // N, N, float(self.eps), _stream(x)))
         return y

@@ -170,7 +170,7 @@ def gdn_chunk(
 
 def short_conv(
     x: torch.Tensor, weight: torch.Tensor, state: Optional[torch.Tensor] = None,
-    activation: Optional[str] = "silu",
+    activation: Optional[str] = "silu", bias: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Causal depthwise conv1d (+SiLU) with CARRY-IN of the previous inputs.
 
@@ -190,7 +190,7 @@ def short_conv(
     st = torch.zeros(B, D, W) if state is None else state.float()
     ext = torch.cat([st.transpose(1, 2), xf], dim=1)                # [B, W+T, D]
     wf = weight.float().reshape(D, W)
-    y = torch.zeros(B, T, D)
+    y = torch.zeros(B, T, D) if bias is None else bias.float().reshape(1, 1, D).expand(B, T, D).clone()   # (convolution.py:128-160: nn.Conv1d bias)
     for j in range(W):
         y = y + ext[:, 1 + j: 1 + j + T, :] * wf[:, j]
     if activation in ("silu", "swish"):
@@ -199,11 +199,19 @@ def short_conv(
     return y, new_state
 
 
-def rmsnorm_swish_gate(x: torch.Tensor, gate: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def rmsnorm_swish_gate(x: torch.Tensor, gate: torch.Tensor, weight: Optional[torch.Tensor], eps: float = 1e-5,
+                       residual: Optional[torch.Tensor] = None, return_residual: bool = False):
     """y = x*rsqrt(mean(x^2)+eps)*w * gate*sigmoid(gate), statistics in fp32.
 
-    fla:modules/fused_norm_gate.py:27-95 with IS_RMS_NORM, ACTIVATION='swish'.
+    fla:modules/fused_norm_gate.py:27-95 with IS_RMS_NORM, ACTIVATION='swish'.  weight None: elementwise_affine=False
+    (HAS_WEIGHT off).  residual: the row is x + residual in fp32 (54-58), which is also what prenorm hands back (59-60).
     """
     xf, gf = x.float(), gate.float()
+    if residual is not None:
+        xf = xf + residual.float()
     rstd = 1.0 / torch.sqrt((xf * xf).mean(-1, keepdim=True) + eps)
-    return xf * rstd * weight.float() * gf * torch.sigmoid(gf)
+    y = xf * rstd
+    if weight is not None:
+        y = y * weight.float()
+    y = y * gf * torch.sigmoid(gf)
+    return (y, xf) if return_residual else y

@@ -237,6 +237,40 @@ def test_rmsnorm_gate_golden():
     assert rms_rel(z["y"], y.float().cpu()) < 5e-3
 
 
+def test_non_default_module_options_reference_vectors():
+    """The options of the fla modules that InfiniteVL leaves at their defaults, against the reference's own outputs
+    (tests/golden/gen_golden_options.py): ShortConvolution(bias=True) prefill + steps with the state bit-exact;
+    FusedRMSNormGated(elementwise_affine=False), residual=, prenorm= (residual_out returned), residual_in_fp32=."""
+    from infinitevl_amd import ops
+    z = load_golden("short_conv_bias")
+    conv = ops.ShortConvolution(64, 4, bias=True, activation="silu").to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        conv.weight.copy_(z["weight"].reshape(64, 1, 4))
+        conv.bias.copy_(z["bias"])
+        y, st = conv(bf(z["x"]).to(DEV), cache=None, output_final_state=True)
+        assert rms_rel(z["y"], y.cpu()) < 5e-3 and torch.equal(st.float().cpu(), z["state"])
+        for i in range(z["xs"].shape[0]):
+            yi, st = conv(bf(z["xs"][i]).to(DEV), cache=st, output_final_state=True)
+            assert rms_rel(z["ys"][i], yi.cpu()) < 5e-3 and torch.equal(st.float().cpu(), z["states"][i])
+    z = load_golden("rmsnorm_gate_options")
+    x, g = bf(z["x"]).to(DEV), bf(z["gate"]).to(DEV)
+    plain = ops.FusedRMSNormGated(256, elementwise_affine=False, eps=float(z["eps"])).to(DEV)
+    assert plain.weight is None and rms_rel(z["y_no_affine"], plain(x, g).cpu()) < 5e-3
+    aff = ops.FusedRMSNormGated(256, eps=float(z["eps"])).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        aff.weight.copy_(z["weight"])
+        res = z["residual"].to(DEV)                                  # fp32, as the reference was given it
+        assert rms_rel(z["y_residual"], aff(x, g, residual=res).cpu()) < 5e-3
+        y, r = aff(x, g, residual=res, prenorm=True)
+        assert rms_rel(z["y_prenorm"], y.cpu()) < 5e-3 and r.dtype == torch.float32 and torch.equal(r.cpu(), z["residual_out"])
+        y, r = aff(x, g, residual=bf(res), prenorm=True)              # bf16 residual stream: residual_out in bf16, the row unrounded
+        assert r.dtype == torch.bfloat16 and rms_rel(z["y_prenorm"], y.cpu()) < 5e-3 and rms_rel(z["residual_out"], r.cpu()) < 5e-3
+        y, r = aff(x, g, prenorm=True, residual_in_fp32=True)
+        assert rms_rel(z["y_prenorm_fp32"], y.cpu()) < 5e-3 and r.dtype == torch.float32 and torch.equal(r.cpu(), z["residual_out_fp32"])
+        y, r = aff(x, g, prenorm=True)                                # no residual, same dtype: the input itself comes back (fused_norm_gate.py:155)
+        assert r is x or torch.equal(r, x)
+
+
 def test_gate_math_vs_oracle():
     from infinitevl_amd import ops
     torch.manual_seed(2)

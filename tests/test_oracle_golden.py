@@ -80,6 +80,27 @@ def test_short_conv_carry_in_is_split_invariant():
         assert torch.equal(st, s_full)
 
 
+def test_non_default_module_options_match_reference():
+    """ShortConvolution(bias=True) and FusedRMSNormGated(elementwise_affine=False) / residual= / prenorm= / residual_in_fp32=
+    (fixtures of tests/golden/gen_golden_options.py: the reference's own modules)."""
+    z = load_golden("short_conv_bias")
+    w, b = z["weight"].reshape(-1, 4), z["bias"]
+    y, st = gdn.short_conv(z["x"], w, None, bias=b)
+    assert rms_rel(z["y"], y) < 2e-6 and torch.equal(st, z["state"])
+    c = st
+    for i in range(z["xs"].shape[0]):
+        yi, c = gdn.short_conv(z["xs"][i], w, c, bias=b)
+        assert rms_rel(z["ys"][i], yi) < 2e-6 and torch.equal(c, z["states"][i])
+    z = load_golden("rmsnorm_gate_options")
+    eps = float(z["eps"])
+    assert rms_rel(z["y_no_affine"], gdn.rmsnorm_swish_gate(z["x"], z["gate"], None, eps)) < 2e-6
+    assert rms_rel(z["y_residual"], gdn.rmsnorm_swish_gate(z["x"], z["gate"], z["weight"], eps, residual=z["residual"])) < 2e-6
+    y, r = gdn.rmsnorm_swish_gate(z["x"], z["gate"], z["weight"], eps, residual=z["residual"], return_residual=True)
+    assert rms_rel(z["y_prenorm"], y) < 2e-6 and torch.equal(r, z["residual_out"])
+    y, r = gdn.rmsnorm_swish_gate(z["x"], z["gate"], z["weight"], eps, return_residual=True)
+    assert rms_rel(z["y_prenorm_fp32"], y) < 2e-6 and torch.equal(r, z["residual_out_fp32"]) and r.dtype == torch.float32
+
+
 def test_rmsnorm_gate_matches_reference():
     z = load_golden("rmsnorm_gate")
     y = gdn.rmsnorm_swish_gate(z["x"], z["gate"], z["weight"], float(z["eps"]))
