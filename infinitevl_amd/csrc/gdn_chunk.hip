@@ -989,7 +989,9 @@ __device__ __forceinline__ void load_h2(const unsigned char* rec, unsigned int i
   load_region<L, h2_pieces(F8), DEV>(rec + R::KDT, img + (unsigned int)R::KDT, lane16);
 }
 
-// Barrier protocol (every wave of the workgroup executes the same sequence PA, P0, P, T(0), M(0), T(1), M(1), ..., F):
+// Barrier protocol (every wave of the workgroup executes the same sequence [PF,] PA, P0, P, T(0), M(0), T(1), M(1), ..., F):
+//   PF    : single-launch forms only: loader 0 -- the workgroup's one polling wave -- has seen the flags of the records the loaders
+//           request first (or its wait failed: abort word 0, every wave leaves)
 //   PA    : the raw value tile of chunk 0 has landed (NCW = 2)
 //   P0    : beta v of chunk 0 is staged (V waves)
 //   P     : H1(0) has landed;  u(0) is in image 0
@@ -1125,6 +1127,8 @@ template <bool PROGRESSIVE>
 __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
   const int nw = PROGRESSIVE ? (nt_seg < 3 ? nt_seg : 3) : nt_seg;         // (all at once: the host keeps nt_seg <= 63)
   const unsigned int* p = lane == 63 ? sy.err : sy.flags + bh * SYNC_HEAD_WORDS + (lane < nw ? lane : 0);
+  // (Three polls in flight, a third of a round trip apart, were measured: the flags are seen earlier, but the extra device-scope
+  // loads slow the pre-pass workgroups they wait for -- 16.3 -> 16.6 us at the step shape.  ONE wave per workgroup polls.)
   for (int spin = 0; spin < SYNC_SPIN_BOUND; ++spin) {
     const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != (lane == 63 ? 0u : sy.nprod));
@@ -1136,9 +1140,10 @@ __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, in
   return false;
 }
 // Abort words of a scan workgroup (LDS, the first dwords of the otherwise unused `dummy` area of the 32-column workgroup):
-// word L = loader L's wait failed (written by every loader before PA, 0 or 1), word 4 = the gate wave's (V wave 0, long
-// calls: 0 before PA, 1 when a later chunk's wait runs out).  Read by every wave behind PA, by the output waves at every chunk
-// step and by the state waves in front of their state store: nothing computed from unseen records leaves the workgroup.
+// word 0 = the wait at the start failed (written by loader 0 in front of the barrier PF, 0 or 1; words 1-3 zero), word 4 = the
+// gate wave's (V wave 0, long calls: 0 before PF, 1 when a later chunk's wait runs out).  Read by every wave behind PF, by the
+// output waves at every chunk step and by the state waves in front of their state store: nothing computed from unseen records
+// leaves the workgroup.
 template <bool F8> __device__ __forceinline__ unsigned int* scan_abort_words(unsigned char* smem) {
   return (unsigned int*)(smem + Img<F8>::dummy(2));
 }
@@ -1181,11 +1186,15 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     constexpr int NB = L == 3 ? 1 : 0;
     load_vt<L, F8>(tc, 0, nt_seg, lane);
     load_vt<L, F8>(tc, 1, nt_seg, lane);
-    const bool seen = scan_wait_records<SYNC == 2>(sy, bh, nt_seg, lane);
-    if (lane == 0) scan_abort_words<F8>(smem)[L] = seen ? 0u : 1u;
-    if (!seen) {                                                 // (wave-uniform) nothing is read from the records: the workgroup stops behind PA
+    // ONE wave of the workgroup (loader 0) polls -- 512 polling waves on the scan's CUs slowed the pre-pass they wait for --
+    // and the barrier PF carries what it saw to every other wave
+    if constexpr (L == 0) {
+      const bool ok = scan_wait_records<SYNC == 2>(sy, bh, nt_seg, lane);
+      if (lane == 0) *(u32x4*)scan_abort_words<F8>(smem) = u32x4{ok ? 0u : 1u, 0u, 0u, 0u};
+    }
+    lds_barrier();                                               // PF: the records the loaders request first are published (or the wait failed)
+    if (scan_aborted<F8, false>(smem)) {                         // (workgroup-uniform) nothing is read from the records: every wave stops here
       wait_vm<0>();
-      lds_barrier();                                             // PA
       return;
     }
 #ifdef IVL_TRACE
@@ -1214,9 +1223,6 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
     else wait_vm<N1 + NVB + NTU + N2 + 2 * NT>();
   }
   lds_barrier();                                               // PA
-  if constexpr (SYNC != 0) {
-    if (scan_aborted<F8, false>(smem)) { wait_vm<0>(); return; }   // another loader's wait failed
-  }
 #ifdef IVL_TRACE
   if (ivl_trace_buf != nullptr && lane == 0 && trace_wg && L == 0) ivl_trace_buf[43] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -1516,6 +1522,10 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   if constexpr (SYNC == 2) {
     if (vw == 0 && lane == 0) scan_abort_words<F8>(smem)[4] = 0u;
   }
+  if constexpr (SYNC != 0) {
+    lds_barrier();                       // PF: loader 0 has seen the flags (or its wait failed)
+    if (scan_aborted<F8, false>(smem)) return;
+  }
   lds_barrier();                         // PA: value tile 0 has landed (NCW = 2)
   landed(S0{});
   conv_stage(0, S0{});                   // beta v of chunk 0
@@ -1724,9 +1734,12 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
         }
       }
     };
+    if constexpr (SYNC != 0) {
+      lds_barrier();                     // PF
+      if (scan_aborted<F8, false>(smem)) return;     // the wait for the records failed: no output from this workgroup, flags left as they are
+    }
     lds_barrier();                       // PA
     if constexpr (SYNC != 0) {
-      if (scan_aborted<F8, false>(smem)) return;     // a loader's wait failed: no output from this workgroup, flags left as they are
       if (SYNC == 1) flags_done();
     }
     lds_barrier();                       // P0
@@ -1874,10 +1887,11 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
     for (int m = 0; m < 4; ++m) uu[m] = *(const u32x2*)(smem + Img<F8>::uslab(NCW) + pair * 2048 + m * 512 + lane * 8);
     egl = *(const float*)(im + R::EGL);
   };
-  lds_barrier();                         // PA
   if constexpr (SYNC != 0) {
+    lds_barrier();                       // PF
     if (scan_aborted<F8, false>(smem)) return;
   }
+  lds_barrier();                         // PA
   lds_barrier();                         // P0
   if constexpr (TILE_OK) {
     if (tiled_in) {                      // (workgroup-uniform) own slab out of the tile: column 16 pair + j, rows 16t + 4g + r
