@@ -142,7 +142,8 @@ struct ScanSync {
   unsigned int* err = nullptr;              // err[0]: sticky error code (0 = healthy); err[1]: (bh << 16) | chunk of the first failure
   unsigned int* host_err = nullptr;         // the same two words in pinned host memory (NULL: not available)
   int BH = 0;
-  unsigned int nprod = 1;                   // pre-pass workgroups per chunk (2: split into a k side and a q side)
+  int nsplit = 0;                           // chunks [0, nsplit) of the segment come from a split pre-pass (a k side and a q side: two
+                                            // increments of their flag), the others from one workgroup (one increment)
 };
 // one lane: record the first failure (device word for the workgroups of this and of later launches, host word for the C ABI)
 __device__ __forceinline__ void sync_fail(const ScanSync& sy, unsigned int code, int bh, int c) {
@@ -1126,12 +1127,14 @@ __device__ __forceinline__ void wait_vm() {
 template <bool PROGRESSIVE>
 __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, int nt_seg, int lane) {
   const int nw = PROGRESSIVE ? (nt_seg < 3 ? nt_seg : 3) : nt_seg;         // (all at once: the host keeps nt_seg <= 63)
-  const unsigned int* p = lane == 63 ? sy.err : sy.flags + bh * SYNC_HEAD_WORDS + (lane < nw ? lane : 0);
+  const int cw = lane < nw ? lane : 0;                                      // the chunk this lane watches
+  const unsigned int want = lane == 63 ? 0u : (cw < sy.nsplit ? 2u : 1u);
+  const unsigned int* p = lane == 63 ? sy.err : sy.flags + bh * SYNC_HEAD_WORDS + cw;
   // (Three polls in flight, a third of a round trip apart, were measured: the flags are seen earlier, but the extra device-scope
   // loads slow the pre-pass workgroups they wait for -- 16.3 -> 16.6 us at the step shape.  ONE wave per workgroup polls.)
   for (int spin = 0; spin < SYNC_SPIN_BOUND; ++spin) {
     const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != (lane == 63 ? 0u : sy.nprod));
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != want);
     if (bad == 0ull) return true;
     if (bad >> 63) return false;                                           // the area has failed before: no use waiting
     __builtin_amdgcn_s_sleep(4);
@@ -1553,12 +1556,13 @@ __device__ __forceinline__ void scan_vwave(const ScanV sv, const unsigned char* 
   auto gate_wait = [&](int c) {
     if (c >= nt_seg || gate_dead) return;
     unsigned int v = gate_val;
-    for (int spin = 0; v != sy.nprod && spin < SYNC_SPIN_BOUND; ++spin) {   // bounded like scan_wait_records
+    const unsigned int want = c < sy.nsplit ? 2u : 1u;
+    for (int spin = 0; v != want && spin < SYNC_SPIN_BOUND; ++spin) {       // bounded like scan_wait_records
       __builtin_amdgcn_s_sleep(4);
       v = __hip_atomic_load(sy.flags + bh * SYNC_HEAD_WORDS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((spin & 31) == 31 && __hip_atomic_load(sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // the area has failed elsewhere
     }
-    if (v != sy.nprod) {                                             // (wave-uniform) tell the workgroup through LDS, the host through the area
+    if (v != want) {                                                 // (wave-uniform) tell the workgroup through LDS, the host through the area
       gate_dead = true;
       if (lane == 0) {
         sync_fail(sy, SYNC_E_GATE, bh, c);
@@ -2037,6 +2041,28 @@ __global__ __launch_bounds__(MODE == 2 ? LONG_THREADS : SINGLE_THREADS) void gdn
   constexpr bool SPLIT = MODE == 1, LONG = MODE == 2;
   const int nside = nt_seg * BH;                       // (chunk, head) pairs of the segment; nprep = pre-pass workgroups of the launch
   int id = (int)blockIdx.x;
+  // MODE 2: the first 2 nsplit BH blocks are STARTERS -- the split pre-pass (a k side and a q side, 512 threads each) of the
+  // chunks the scan needs first (sy.nsplit = 5: measured 3 / 4 / 5 / 6 -> 90 / 87.8 / 86.8 / 87.0 us at T = 4096, round 3: 97):
+  // they publish after ~7 us where a round of the two-body persistent workgroups takes ~16, and their CUs go to the blocks that
+  // were not resident at the start (the grid is larger than the chip by these blocks; the scan workgroups, last in id order,
+  // need their CUs only when the first records exist).  ids: q sides of chunk 0 | k sides | q sides of chunks 1.. (as in MODE 1).
+  const int nstart = LONG ? 2 * sy.nsplit * BH : 0;
+  if (LONG && id < nstart) {
+    if (threadIdx.x >= 512) return;
+    const int nks = sy.nsplit * BH;
+    bool qside = false;
+    if (id < BH) { qside = true; }
+    else if (id < BH + nks) { id -= BH; }
+    else { qside = true; id -= nks; }
+    const int ci = id / BH, bh = id % BH;              // chunk-major
+    unsigned int* done = sy.flags + bh * SYNC_HEAD_WORDS + ci;
+    if (!qside)
+      gdn_chunk_prepare_body<F8, true, true, 1>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh, &sy);
+    else
+      gdn_chunk_prepare_body<F8, true, true, 2>(smem, ci, bh, nullptr, nullptr, nullptr, nullptr, pf, ws, T, H, t_seg0, nt_seg, 1, done, sy.kread + bh, &sy);
+    return;
+  }
+  id -= nstart;
   if (id < nprep) {
     if constexpr (LONG) {
       // Two bodies per workgroup, threads [0, 512) and [512, 1024), each with its own 70 KB of LDS and its own (chunk, head)
@@ -2055,7 +2081,7 @@ __global__ __launch_bounds__(MODE == 2 ? LONG_THREADS : SINGLE_THREADS) void gdn
 #else
       const unsigned int* kp = (const unsigned int*)&pf;
 #endif
-      for (int w = 2 * id + half; w < nside; w += 2 * nprep) {   // (the publish at the end of the body is a workgroup barrier: LDS is free again)
+      for (int w = sy.nsplit * BH + 2 * id + half; w < nside; w += 2 * nprep) {   // (the publish at the end of the body is a workgroup barrier: LDS is free again)
         asm volatile("" : "+s"(kp));
         PrepFused pfl;
         {
@@ -2243,8 +2269,9 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   const bool can_sync = pf != nullptr && sync != nullptr && ncw == 2 && BH <= SYNC_MAX_HEADS;
   bool single = can_sync && NT <= 63 && NT * BH + (16 / 2) * BH <= resident;
   // long calls: one launch per segment, persistent pre-pass workgroups beside the scan workgroups -- at least as many of them
-  // (an even number of (chunk, head) pairs per segment: a pre-pass workgroup runs two bodies side by side)
-  bool overlap = can_sync && !single && 2 * 8 * BH <= resident && (BH % 2 == 0 || (segc % 2 == 0 && NT % 2 == 0));
+  // (an even number of (chunk, head) pairs behind the starters of every segment: a persistent pre-pass workgroup runs two bodies
+  // side by side; with an odd B*H that needs segments of an odd number of chunks > 3, which 64-chunk segments are not)
+  bool overlap = can_sync && !single && 2 * 8 * BH <= resident && BH % 2 == 0;
 #ifdef IVL_TRACE
   single = single && g_gdn_single != 0;
   overlap = overlap && g_gdn_single != 0 && g_gdn_single != 3;
@@ -2253,7 +2280,7 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   if (can_sync) {
     sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.err = sync + SYNC_ERR_WORD;
     sy.host_err = g_host_status_dev[device_index()];
-    sy.BH = BH; sy.nprod = 1u;
+    sy.BH = BH; sy.nsplit = 0;
   }
   const int lds1 = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
   if (single) {
@@ -2261,7 +2288,7 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
 #ifdef IVL_TRACE
     split = split && g_gdn_single != 2;
 #endif
-    sy.nprod = split ? 2u : 1u;
+    sy.nsplit = split ? SYNC_HEAD_WORDS : 0;
     if (split)
       hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 1>), dim3(2 * NT * BH + 8 * BH), dim3(SINGLE_THREADS), lds1, st, *pf, wsb,
                          (bf16_t*)o, sv, h0, h0_dtype, ht, ht_dtype, T, H, BH, 0, NT, 2 * NT * BH, scale, sy);
@@ -2278,9 +2305,13 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
       const int hin_dt = first ? h0_dtype : IVL_F32;
       void* hout = last ? ht : (void*)carry;
       const int hout_dt = last ? ht_dtype : IVL_F32;
+#ifndef IVL_AB_NSTART
+#define IVL_AB_NSTART 5
+#endif
+      sy.nsplit = nseg < IVL_AB_NSTART ? nseg : IVL_AB_NSTART;     // starter chunks: at least what the scan's loaders request before the first chunk step
       int nprep = resident - 8 * BH;                               // persistent pre-pass workgroups: what the chip holds beside the scan
-      if (nprep > nseg * BH / 2) nprep = nseg * BH / 2;            // (two chunk-head pairs per workgroup and round)
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(nprep + 8 * BH), dim3(LONG_THREADS), lds1, st, *pf, wsb,
+      if (nprep > (nseg - sy.nsplit) * BH / 2) nprep = (nseg - sy.nsplit) * BH / 2;   // (two chunk-head pairs per workgroup and round)
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(2 * sy.nsplit * BH + nprep + 8 * BH), dim3(LONG_THREADS), lds1, st, *pf, wsb,
                          (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, nprep, scale, sy);
       int rc = check_launch("ivl_gdn_chunk_fused_fwd(overlapped launch)");
       if (rc != IVL_OK) return rc;

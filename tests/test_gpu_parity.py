@@ -1836,7 +1836,7 @@ def test_gdn_single_launch_under_a_co_running_stream():
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "256,1000,4300", "--iters", "40", "--co-stream"],
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "256,1000,4300", "--iters", "150", "--co-stream"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "GDN_SYNC_STRESS PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
@@ -1851,7 +1851,7 @@ def test_gdn_single_launch_two_processes_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         bar = os.path.join(td, "go")
-        procs = [subprocess.Popen([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "1000,4300,256", "--iters", "40",
+        procs = [subprocess.Popen([_sys.executable, os.path.join(root, "tools", "gdn_sync_stress.py"), "--T", "1000,4300,256", "--iters", "150",
                                    "--barrier-file", bar, "--nprocs", "2", "--seed", str(i)],
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
         outs = [p.communicate(timeout=900) for p in procs]
