@@ -58,6 +58,10 @@ def main():
         ok = all(checks.values())
         if not ok:
             print("SP_CHECK details:", checks, cache.get_seq_length(), ref_cache.get_seq_length(), flush=True)
+        if len(sys.argv) > 2 and sys.argv[1] == "--dump":        # for the test's oracle comparison (tests/ may use oracle/, tools/ may not)
+            torch.save({"state_dict": {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, "xs": xs.float().cpu(),
+                        "h_last_segment": h.float().cpu(), "first": first, "last": last, "window": window, "layers": len(lt), "heads": heads},
+                       sys.argv[2])
         print("SP_CHECK", "PASS" if ok else "FAIL", flush=True)
     ivd.barrier()
     torch.distributed.destroy_process_group()
