@@ -593,6 +593,7 @@ def main():
     #      gloo debug backend).  Checked on the last rank against its own single-rank run of the same call sequence.
     sp = None
     if world > 1 and not args.no_sp:
+      try:                                   # (never lose the headline line over the extra leg: an exception is recorded instead)
         Ts = args.sp_tokens
         gsp = torch.Generator(device=device).manual_seed(4242)           # the same sequence on every rank
         xs_all = (torch.randn(1, world * Ts, cfg.hidden_size, device=device, generator=gsp) * 0.02).to(torch.bfloat16)
@@ -635,6 +636,8 @@ def main():
               "single_rank_ms_same_calls": check.get("single_rank_ms"), "speedup_vs_single_rank": (check["single_rank_ms"] / sp_ms[-1]) if check.get("single_rank_ms") else None,
               "logits_finite": check.get("finite")}
         del cache_sp, xs_all
+      except Exception as e:                 # noqa: BLE001
+        sp = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- fp8 leg (rank 0, reported beside the headline, never mixed into `value`): BASELINE.json configs[4] -- the same
     #      steady-state streaming step and decode step with e4m3 operands in the GDN chunk scan / SWA decode step
