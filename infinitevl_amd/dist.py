@@ -178,17 +178,20 @@ def sequence_parallel_prefill(model: Callable, inputs_embeds: torch.Tensor, cach
             recvs[i] = _Pending(cache.layers[i].carried_tensors(), rank - 1, recv=True)
 
     def before(i: int) -> None:
-        # layer i's state was requested one layer earlier (its tensors are not touched until now), so the transfer ran
-        # under layer i-1's mixer and MLP; layer i+1's is requested now and runs under this layer's
+        # layer i's state was requested right behind layer i-1's send (its tensors are not touched until now), so the transfer
+        # runs under layer i-1's MLP and whatever the sender still has to do before its mixer i
         if has_prev:
             post_recv(i)
             recvs.pop(i).wait()
             cache.layers[i].import_carried(first_token)
-            post_recv(i + 1)
 
     def after(i: int) -> None:
         if has_next:                              # non-blocking: the MLP of this layer overlaps the transfer
             sends.append(_Pending(cache.layers[i].carried_tensors(), rank + 1, recv=False))
+        # the next layer's receive goes out BEHIND this layer's send: RCCL runs the batches of a communicator in issue order,
+        # and a receive posted first would hold the send back until rank r-1 has finished the NEXT layer (two layer-times per
+        # hop of the wavefront instead of one)
+        post_recv(i + 1)
 
     if T == 0:                                   # nothing to compute: pass every layer's state through
         for i in range(n_layers):
