@@ -16,9 +16,9 @@ typedef __bf16 bf16_native2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) { const bf16_native2 v = {(__bf16)lo, (__bf16)hi}; return __builtin_bit_cast(unsigned int, v); }
 __device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) { mfma_bf16x8 r; __builtin_memcpy(&r, &v, 16); return r; }
 constexpr int KS = 272, VS = 320, KT = 64, D = 128;
-constexpr int K_BYTES = KT * KS, V_OFF = K_BYTES, LDS = K_BYTES + KT * VS;
+constexpr int K_BYTES = KT * KS, V_OFF = K_BYTES, Q_OFF = K_BYTES + KT * VS, LDS = Q_OFF + 256 * KS;
 
-template <int PIPE>
+template <int PIPE, bool QLDS>
 __global__ __launch_bounds__(256, 1) void attn_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                     bf16_t* __restrict__ o, int ntiles, float sc) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
@@ -32,10 +32,18 @@ __global__ __launch_bounds__(256, 1) void attn_proto(const bf16_t* __restrict__ 
   }
   const int row0 = (blockIdx.x * 4 + wave) * 64;
   u32x4 qf[2][8];
+  if constexpr (QLDS) {
+    for (int i = tid; i < 256 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      *(u32x4*)(smem + Q_OFF + r * KS + c * 16) = *(const u32x4*)(q + (size_t)(blockIdx.x * 256 + r) * D + c * 8);
+    }
+  } else {
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int kd = 0; kd < 8; ++kd) qf[qb][kd] = *(const u32x4*)(q + (size_t)(row0 + 32 * qb + l31) * D + 16 * kd + 8 * hi5);
+      for (int kd = 0; kd < 8; ++kd) qf[qb][kd] = *(const u32x4*)(q + (size_t)(row0 + 32 * qb + l31) * D + 16 * kd + 8 * hi5);
+  }
+  const int q_off = Q_OFF + (wave * 64 + l31) * KS + 16 * hi5;
   f32x16 oacc[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -56,8 +64,10 @@ __global__ __launch_bounds__(256, 1) void attn_proto(const bf16_t* __restrict__ 
 #pragma unroll
     for (int kd = 0; kd < 8; ++kd) {
       const u32x4 fr = *(const u32x4*)(smem + 32 * kh * KS + k_off + 32 * kd);
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr), mf(qf[0][kd]), s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr), mf(qf[1][kd]), s[1], 0, 0, 0);
+      const u32x4 q0 = QLDS ? *(const u32x4*)(smem + q_off + 32 * kd) : qf[0][kd];
+      const u32x4 q1 = QLDS ? *(const u32x4*)(smem + q_off + 32 * KS + 32 * kd) : qf[1][kd];
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr), mf(q0), s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr), mf(q1), s[1], 0, 0, 0);
     }
   };
   auto softmax_half = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) {
@@ -139,7 +149,8 @@ __global__ __launch_bounds__(256, 1) void attn_proto(const bf16_t* __restrict__ 
 }
 extern "C" int attn_proto_launch(const void* q, const void* k, const void* v, void* o, int rows, int ntiles, float sc, int pipe, void* stream) {
   dim3 grid(rows / 256), block(256);
-  if (pipe) hipLaunchKernelGGL(attn_proto<1>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
-  else hipLaunchKernelGGL(attn_proto<0>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+#define GO(P, Q) { (void)hipFuncSetAttribute((const void*)attn_proto<P, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 0); \
+    hipLaunchKernelGGL((attn_proto<P, Q>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc); }
+  if (pipe == 0) GO(0, false) else if (pipe == 1) GO(1, false) else if (pipe == 2) GO(0, true) else GO(1, true)
   return (int)hipGetLastError();
 }
