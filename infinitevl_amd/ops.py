@@ -100,14 +100,19 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
     assert len(beta.shape) == 3, "beta must be of shape [B, T, H]"                       # chunk.py:353
     if q.dtype != torch.bfloat16:
         raise ValueError(f"infinitevl_amd GDN kernels are built for bf16 activations, got {q.dtype}")
+    B, T, H, K = k.shape
+    V = v.shape[-1]
+    NS = B                                                                                # number of sequences = number of states
     if cu_seqlens is not None:
         if q.shape[0] != 1:                                                               # chunk.py:355-360
             raise ValueError(
                 f"The batch size is expected to be 1 rather than {q.shape[0]} when using `cu_seqlens`."
                 f"Please flatten variable-length inputs before processing.")
-        raise NotImplementedError("variable-length (cu_seqlens) inputs are not used by InfiniteVL (std:1223)")
-    B, T, H, K = k.shape
-    V = v.shape[-1]
+        NS = len(cu_seqlens) - 1
+        if initial_state is not None and initial_state.shape[0] != NS:                    # chunk.py:365-369
+            raise ValueError(
+                f"The number of initial states is expected to be equal to the number of input sequences, "
+                f"i.e., {NS} rather than {initial_state.shape[0]}.")
     if not (q.shape[2] == k.shape[2] == v.shape[2] == g.shape[2] == beta.shape[2]):
         raise ValueError(f"q, k, v, g, beta must share the head count (got {q.shape[2]}, {k.shape[2]}, {v.shape[2]}, "
                          f"{g.shape[2]}, {beta.shape[2]}): grouped key/value heads are not supported by the kernels")
@@ -126,18 +131,44 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
         if initial_state.dtype not in _DT_CODE:
             initial_state = initial_state.float()
         initial_state = initial_state.contiguous()
-        if tuple(initial_state.shape) != (B, H, K, V):
-            raise ValueError(f"initial_state shape {tuple(initial_state.shape)} != {(B, H, K, V)}")
+        if tuple(initial_state.shape) != (NS, H, K, V):
+            raise ValueError(f"initial_state shape {tuple(initial_state.shape)} != {(NS, H, K, V)}")
     ht = None
     if final_state_out is not None:
-        if tuple(final_state_out.shape) != (B, H, K, V) or final_state_out.dtype not in _DT_CODE \
+        if tuple(final_state_out.shape) != (NS, H, K, V) or final_state_out.dtype not in _DT_CODE \
                 or not final_state_out.is_contiguous():
             raise ValueError("final_state_out must be a contiguous [B,H,K,V] fp32/bf16 tensor")
         ht = final_state_out
     elif output_final_state:
-        ht = torch.empty(B, H, K, V, dtype=torch.float32, device=q.device)               # chunk_delta_h.py:291
+        ht = torch.empty(NS, H, K, V, dtype=torch.float32, device=q.device)              # chunk_delta_h.py:291
     o = torch.empty(B, T, H, V, dtype=q.dtype, device=q.device)
     return q, k, v, g, beta, float(scale), initial_state, ht, o, (B, T, H, K, V)
+
+
+def _varlen_segments(cu_seqlens: torch.Tensor, T: int):
+    """[(first, last)) token ranges of the flattened sequences (fla:ops/utils/index.py: the reference, too, reads the
+    offsets on the host to lay out its chunk grid).  One host read of `cu_seqlens`: not capturable in a hipGraph."""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("variable-length inputs read cu_seqlens on the host: not inside a hipGraph capture")
+    cu = [int(x) for x in cu_seqlens.tolist()]
+    if len(cu) < 2 or cu[0] != 0 or cu[-1] != T or any(b_ < a for a, b_ in zip(cu[:-1], cu[1:])):
+        raise ValueError(f"cu_seqlens must rise from 0 to the flattened length {T} (got {cu[:4]}...{cu[-1:]})")
+    return list(zip(cu[:-1], cu[1:]))
+
+
+def _gdn_varlen(entry, q, k, v, g, beta, o, h0, ht, segs, H, K, V, scale, l2norm, extra):
+    """Variable-length inputs (cu_seqlens; fla:ops/gated_delta_rule/chunk.py:355-369, chunk_delta_h.py:32-124): the sequences
+    are independent -- own initial / final state, chunks counted from the sequence's own first token -- so each one is one call
+    of the kernel on its slice of the flattened [1, T, ...] tensors (contiguous views; no copies).  InfiniteVL itself never
+    takes this path (std:1223 nulls the mask)."""
+    for i, (a, b_) in enumerate(segs):
+        hi = None if h0 is None else h0[i:i + 1]
+        ho = None if ht is None else ht[i:i + 1]
+        if b_ == a:                                   # empty sequence: the state passes through
+            if ho is not None:
+                ho.zero_() if hi is None else ho.copy_(hi)
+            continue
+        entry(q[:, a:b_], k[:, a:b_], v[:, a:b_], g[:, a:b_], beta[:, a:b_], o[:, a:b_], hi, ho, b_ - a, H, K, V, scale, l2norm, *extra)
 
 
 def _from_head_first(q, k, v, g, beta, cu_seqlens):
@@ -163,11 +194,18 @@ def fused_recurrent_gated_delta_rule(
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
     lib = _lib.load()
-    _lib.check(lib.ivl_gdn_recurrent_fwd(
-        _p(q), _p(k), _p(v), _p(g), _p(beta), _p(o),
-        _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
-        _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
-        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), _stream(q)))
+
+    def entry(q_, k_, v_, g_, b_, o_, hi, ho, Tn, H_, K_, V_, sc, l2):
+        _lib.check(lib.ivl_gdn_recurrent_fwd(
+            _p(q_), _p(k_), _p(v_), _p(g_), _p(b_), _p(o_),
+            _p(hi), _DT_CODE[hi.dtype] if hi is not None else IVL_F32,
+            _p(ho), _DT_CODE[ho.dtype] if ho is not None else IVL_F32,
+            q_.shape[0], Tn, H_, K_, V_, sc, l2, _stream(q_)))
+    if cu_seqlens is not None:
+        _gdn_varlen(entry, q, k, v, g, beta, o, h0, ht, _varlen_segments(cu_seqlens, T), H, K, V, scale,
+                    int(bool(use_qk_l2norm_in_kernel)), ())
+    else:
+        entry(q, k, v, g, beta, o, h0, ht, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)))
     return (o.transpose(1, 2) if head_first else o), ht
 
 
@@ -184,15 +222,24 @@ def chunk_gated_delta_rule(
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
     lib = _lib.load()
-    nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, T, H, K, V)
+    segs = _varlen_segments(cu_seqlens, T) if cu_seqlens is not None else None
+    Tmax = max([b_ - a for a, b_ in segs] + [1]) if segs is not None else T
+    nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, Tmax, H, K, V)
     if nbytes == 0:
         raise ValueError(f"chunk_gated_delta_rule: unsupported head shape K={K}, V={V} (built for 128/256)")
     ws = get_workspace(nbytes, q.device, "gdn")
-    _lib.check(lib.ivl_gdn_chunk_fwd(
-        _p(q), _p(k), _p(v), _p(g), _p(beta), _p(o),
-        _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32,
-        _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
-        B, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), mma_code(mma_dtype), _p(ws), ws.numel(), _stream(q)))
+    mma = mma_code(mma_dtype)
+
+    def entry(q_, k_, v_, g_, b_, o_, hi, ho, Tn, H_, K_, V_, sc, l2):
+        _lib.check(lib.ivl_gdn_chunk_fwd(
+            _p(q_), _p(k_), _p(v_), _p(g_), _p(b_), _p(o_),
+            _p(hi), _DT_CODE[hi.dtype] if hi is not None else IVL_F32,
+            _p(ho), _DT_CODE[ho.dtype] if ho is not None else IVL_F32,
+            q_.shape[0], Tn, H_, K_, V_, sc, l2, mma, _p(ws), ws.numel(), _stream(q_)))
+    if segs is not None:
+        _gdn_varlen(entry, q, k, v, g, beta, o, h0, ht, segs, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)), ())
+    else:
+        entry(q, k, v, g, beta, o, h0, ht, T, H, K, V, scale, int(bool(use_qk_l2norm_in_kernel)))
     return (o.transpose(1, 2) if head_first else o), ht
 
 
@@ -429,7 +476,28 @@ class ShortConvolution(nn.Module):
                 output_final_state: bool = False, cu_seqlens: Optional[torch.Tensor] = None, **kwargs):
         _need_gpu(x)
         if cu_seqlens is not None:
-            raise NotImplementedError("variable-length inputs are not used by InfiniteVL (std:1223)")
+            # flattened variable-length batch (convolution.py:216-231): x [1, T, D], cache [N, D, W]; the sequences do not see
+            # each other's tokens -- one call per sequence on its slice (InfiniteVL never takes this path: std:1223)
+            if x.shape[0] != 1:
+                raise ValueError(f"The batch size is expected to be 1 rather than {x.shape[0]} when using `cu_seqlens`.")
+            segs = _varlen_segments(cu_seqlens, x.shape[1])
+            if cache is not None and cache.shape[0] != len(segs):
+                raise ValueError(f"conv cache holds {cache.shape[0]} sequences, cu_seqlens {len(segs)}")
+            if mask is not None:
+                x = x.mul(mask.unsqueeze(-1))
+            if x.dtype != torch.bfloat16:
+                raise ValueError(f"ShortConvolution kernel is built for bf16, got {x.dtype}")
+            x = x.contiguous()
+            D, W = x.shape[2], self.kernel_size[0]
+            state_in = cache
+            if cache is None and output_final_state:
+                cache = torch.zeros(len(segs), D, W, dtype=x.dtype, device=x.device)
+            y = torch.empty_like(x)
+            for i, (a, b_) in enumerate(segs):
+                if b_ > a:
+                    self._launch(x[:, a:b_], y[:, a:b_], None if state_in is None else state_in[i:i + 1],
+                                 None if cache is None else cache[i:i + 1], 1, b_ - a, D, W)
+            return y, cache
         if mask is not None:
             x = x.mul(mask.unsqueeze(-1))
         if x.dtype != torch.bfloat16:
@@ -444,18 +512,21 @@ class ShortConvolution(nn.Module):
                                   or tuple(cache.shape) != (B, D, W)):
             raise ValueError("conv cache must be a contiguous bf16 [N,D,W] tensor")
         y = torch.empty_like(x)
+        self._launch(x, y, state_in, cache, B, T, D, W)
+        return y, cache
+
+    def _launch(self, x, y, state_in, state_out, B, T, D, W) -> None:
         w = self.weight
         if w.dtype != torch.bfloat16:
             w = w.to(torch.bfloat16)
         if self.bias is not None:
             _lib.check(_lib.load().ivl_short_conv_bias_fwd(
-                _p(x), _p(w.contiguous()), _p(self.bias.to(torch.bfloat16).contiguous()), _p(state_in), _p(y), _p(cache), B, T, D, W,
+                _p(x), _p(w.contiguous()), _p(self.bias.to(torch.bfloat16).contiguous()), _p(state_in), _p(y), _p(state_out), B, T, D, W,
                 int(self.activation is not None), _stream(x)))
-            return y, cache
-        _lib.check(_lib.load().ivl_short_conv_fwd(
-            _p(x), _p(w.contiguous()), _p(state_in), _p(y), _p(cache), B, T, D, W,
-            int(self.activation is not None), _stream(x)))
-        return y, cache
+        else:
+            _lib.check(_lib.load().ivl_short_conv_fwd(
+                _p(x), _p(w.contiguous()), _p(state_in), _p(y), _p(state_out), B, T, D, W,
+                int(self.activation is not None), _stream(x)))
 
     def step(self, x: torch.Tensor, cache: torch.Tensor):
         return self.forward(x, cache=cache, output_final_state=True)

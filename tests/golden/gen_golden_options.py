@@ -62,5 +62,31 @@ def main():
          y_prenorm_fp32=y_pre32, residual_out_fp32=r_pre32, eps=np.float32(1e-5))
 
 
+def gen_varlen(ns):
+    """cu_seqlens inputs of the two GDN operators (fla:ops/gated_delta_rule/chunk.py:355-369, fused_recurrent.py:296-312):
+    four sequences of 70 / 100 / 1 / 79 tokens flattened into one [1, 250, ...] batch, one initial state each."""
+    from gen_golden import gdn_inputs
+    cu = torch.tensor([0, 70, 170, 171, 250], dtype=torch.long)
+    q, k, v, g, beta, _ = gdn_inputs(7, 1, 250, 2, 128, 256, False)
+    h0 = snap(torch.randn(4, 2, 128, 256, generator=torch.Generator().manual_seed(8)))
+    scale = 128 ** -0.5
+    qn, kn = ns.l2norm.l2norm_fwd(q.contiguous()), ns.l2norm.l2norm_fwd(k.contiguous())
+    import triton
+    idx = torch.cat([torch.arange(n) for n in triton.cdiv(cu[1:] - cu[:-1], 64).tolist()])          # chunk.py:207-214
+    idx = torch.stack([idx.eq(0).cumsum(0) - 1, idx], 1).to(cu)
+    out = ns.chunk.chunk_gated_delta_rule_fwd(qn, kn, v.contiguous(), g.contiguous(), beta.contiguous(), scale, h0, True,
+                                              offsets=cu, indices=idx, head_first=False)
+    o_c, ht_c = out[1], out[-1]
+    o_r, ht_r = ns.recurrent.fused_recurrent_gated_delta_rule(q, k, v, g, beta, scale=scale, initial_state=h0, output_final_state=True,
+                                                              cu_seqlens=cu, head_first=False, use_qk_l2norm_in_kernel=True)
+    save("gdn_varlen", q_bf16bits=bits(q), k_bf16bits=bits(k), v_bf16bits=bits(v), beta_bf16bits=bits(beta), g=g,
+         h0_bf16bits=bits(h0), cu_seqlens=cu.numpy(), o_chunk=o_c.float(), ht_chunk=ht_c.float(), o_recurrent=o_r.float(),
+         ht_recurrent=ht_r.float())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "varlen":
+        gen_varlen(load_reference_fla())
+    else:
+        main()
+        gen_varlen(load_reference_fla())

@@ -146,6 +146,42 @@ def test_gdn_chunk_equals_recurrent_kernel_at_full_width():
     assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 5e-3 and rms_rel(s2.cpu(), s1.cpu()) < 5e-3
 
 
+def test_gdn_varlen_reference_vectors():
+    """cu_seqlens inputs of both GDN operators against the reference's own outputs (4 flattened sequences of 70 / 100 / 1 / 79
+    tokens, one initial state each) and, bit for bit, against the same sequences as separate calls; fla's argument checks."""
+    from infinitevl_amd import ops
+    z = load_golden("gdn_varlen")
+    cu = torch.from_numpy(np.asarray(z["cu_seqlens"])).to(DEV)
+    q, k, v, beta = (bf(z[n]).to(DEV) for n in ("q", "k", "v", "beta"))
+    g, h0 = z["g"].to(DEV), z["h0"].to(DEV)
+    for mode, fn in (("chunk", ops.chunk_gated_delta_rule), ("recurrent", ops.fused_recurrent_gated_delta_rule)):
+        o, ht = fn(q, k, v, g, beta, initial_state=h0, output_final_state=True, cu_seqlens=cu, use_qk_l2norm_in_kernel=True)
+        assert tuple(ht.shape) == (4, 2, 128, 256) and ht.dtype == torch.float32
+        assert rms_rel(z["o_" + mode], o.float().cpu()) < 5e-3 and rms_rel(z["ht_" + mode], ht.cpu()) < 5e-3, mode
+        bounds = [int(x) for x in z["cu_seqlens"]]
+        for i, (a, b_) in enumerate(zip(bounds[:-1], bounds[1:])):
+            oi, hti = fn(q[:, a:b_].contiguous(), k[:, a:b_].contiguous(), v[:, a:b_].contiguous(), g[:, a:b_].contiguous(),
+                         beta[:, a:b_].contiguous(), initial_state=h0[i:i + 1], output_final_state=True, use_qk_l2norm_in_kernel=True)
+            assert torch.equal(oi, o[:, a:b_]) and torch.equal(hti, ht[i:i + 1]), (mode, i)
+    with pytest.raises(ValueError, match="batch size is expected to be 1"):
+        ops.chunk_gated_delta_rule(q.repeat(2, 1, 1, 1), k.repeat(2, 1, 1, 1), v.repeat(2, 1, 1, 1), g.repeat(2, 1, 1), beta.repeat(2, 1, 1), cu_seqlens=cu)
+    with pytest.raises(ValueError, match="number of initial states"):
+        ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=h0[:3], cu_seqlens=cu)
+    with pytest.raises(ValueError, match="cu_seqlens must rise"):
+        ops.chunk_gated_delta_rule(q, k, v, g, beta, cu_seqlens=torch.tensor([0, 70, 200], device=DEV))
+    # an empty sequence passes its state through; the short convolution takes the same offsets
+    cu2 = torch.tensor([0, 70, 70, 250], device=DEV)
+    o_c, _ = ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=h0, output_final_state=True, cu_seqlens=cu, use_qk_l2norm_in_kernel=True)
+    o2, ht2 = ops.chunk_gated_delta_rule(q, k, v, g, beta, initial_state=h0[:3], output_final_state=True, cu_seqlens=cu2, use_qk_l2norm_in_kernel=True)
+    assert torch.equal(ht2[1], h0[1]) and torch.equal(o2[:, :70], o_c[:, :70])
+    conv = ops.ShortConvolution(64, 4, activation="silu").to(DEV, torch.bfloat16)
+    x = bf(torch.randn(1, 250, 64, device=DEV))
+    y, st = conv(x, output_final_state=True, cu_seqlens=cu)
+    for i, (a, b_) in enumerate(zip(bounds[:-1], bounds[1:])):
+        yi, sti = conv(x[:, a:b_].contiguous(), output_final_state=True)
+        assert torch.equal(yi, y[:, a:b_]) and torch.equal(sti[0], st[i])
+
+
 def test_gdn_head_first_layout_equals_time_major():
     """fla's deprecated head_first=True layout ([B,H,T,.], chunk.py:361-373) is accepted and rearranged."""
     from infinitevl_amd import ops

@@ -80,6 +80,19 @@ def test_short_conv_carry_in_is_split_invariant():
         assert torch.equal(st, s_full)
 
 
+def test_gdn_varlen_matches_reference():
+    """cu_seqlens inputs (fixture: the vendored kernels with offsets / indices, gen_golden_options.py): by definition the
+    sequences are independent, so the oracle is the per-sequence rule on each slice with the sequence's own state."""
+    z = load_golden("gdn_varlen")
+    cu = [int(x) for x in z["cu_seqlens"]]
+    for mode in ("chunk", "recurrent"):
+        for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+            fn = gdn.gdn_chunk if mode == "chunk" else gdn.gdn_recurrent
+            o, ht = fn(z["q"][:, a:b], z["k"][:, a:b], z["v"][:, a:b], z["g"][:, a:b], z["beta"][:, a:b], initial_state=z["h0"][i:i + 1])
+            assert rms_rel(z["o_" + mode][:, a:b], o) < 2e-5, (mode, i)
+            assert rms_rel(z["ht_" + mode][i:i + 1], ht) < 2e-5, (mode, i)
+
+
 def test_non_default_module_options_match_reference():
     """ShortConvolution(bias=True) and FusedRMSNormGated(elementwise_affine=False) / residual= / prenorm= / residual_in_fp32=
     (fixtures of tests/golden/gen_golden_options.py: the reference's own modules)."""
