@@ -1882,6 +1882,45 @@ def test_gdn_single_launch_reports_a_wait_that_runs_out(T, chunk):
         ops._GDN_SYNC.pop((area.device.index, id(area)), None)
 
 
+def test_graphed_step_surfaces_a_failed_wait_and_recovers():
+    """Harness level: a replayed graph whose single-launch GDN call cannot complete (its flag words were overwritten) does not
+    hand back garbage silently -- GraphedStep.step() raises IvlError(IVL_ERR_SYNC) (at the failing step or the one after: the
+    status word is read without a device synchronisation), and after ops.gdn_sync_reset() + a cache reset the same graph
+    streams again and equals an undisturbed run."""
+    from infinitevl_amd import ops
+    from infinitevl_amd._lib import IVL_ERR_SYNC, IvlError
+    from infinitevl_amd.harness import GraphedStep
+    stack, hc, _, _ = _small_stack(window=96)
+    T = 128
+    xs = [bf(torch.randn(1, T, hc.hidden_size, device=DEV) * 0.5) for _ in range(3)]
+    ref_cache = stack.allocate_inference_cache(1)
+    with torch.no_grad():
+        ref = [stack(inputs_embeds=x, past_key_values=ref_cache, logits_to_keep=1)[0].clone() for x in xs]
+    cache = stack.allocate_inference_cache(1)
+    gs = GraphedStep(stack, cache, 1, T, logits_to_keep=1)
+    gs.capture()
+    try:
+        h0, _ = gs.step(xs[0])
+        torch.cuda.synchronize()
+        assert torch.equal(h0, ref[0])
+        gs._sync.view(torch.int32)[0] = 9                      # head 0, chunk 0: can never equal the producer count
+        with pytest.raises(IvlError) as ei:
+            gs.step(xs[1])
+            torch.cuda.synchronize()
+            gs.step(xs[2])                                      # (the failure of the previous replay is visible by now at the latest)
+        assert ei.value.code == IVL_ERR_SYNC
+        torch.cuda.synchronize()
+        ops.gdn_sync_reset(DEV)
+        gs.reset()
+        for x, r in zip(xs, ref):
+            h, _ = gs.step(x)
+            torch.cuda.synchronize()
+            assert torch.equal(h, r)
+    finally:
+        torch.cuda.synchronize()
+        ops.gdn_sync_reset(DEV)
+
+
 def test_gdn_single_launch_under_a_co_running_stream():
     """Single-launch forms (step shape and long calls) while a second stream keeps the chip full of streaming kernels of uneven
     length: bit-equal to the two-launch form, no wait runs out, flags left cleared (tools/gdn_sync_stress.py)."""
