@@ -117,10 +117,72 @@ __global__ __launch_bounds__(256, 1) void attn_proto(const bf16_t* __restrict__ 
         oacc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fv), mf(pf[1][ks]), oacc[1][mt], 0, 0, 0);
       }
   };
+  // --- pieces of the hand-interleaved schedule (PIPE == 2): the row-maximum / rescale step (may branch) is separate from the
+  //     exponentials + packing (straight-line VALU) so that the latter can be interleaved with the other half's MFMAs
+  auto max_half = [&](f32x16 (&s)[2], float (&mu)[2]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float rmax = fmaxf(s[qb][0], s[qb][1]);
+#pragma unroll
+      for (int r = 2; r < 16; ++r) rmax = fmaxf(rmax, s[qb][r]);
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+      rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+      const float m_new = fmaxf(m_run[qb], rmax);
+      if (__any(m_new > m_run[qb] + 8.0f)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) oacc[qb][mt] *= alpha;
+        l_run[qb] *= alpha;
+        m_run[qb] = m_new;
+      }
+      mu[qb] = m_run[qb];
+    }
+  };
+  auto exp_half = [&](f32x16 (&s)[2], const float (&mu)[2], u32x4 (&pf)[2][2]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float rsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][r], sc, -mu[qb]));
+        s[qb][r] = p;
+        rsum += p;
+      }
+      l_run[qb] += rsum;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        pf[qb][ks] = u32x4{pack2bf(s[qb][8 * ks + 0], s[qb][8 * ks + 1]), pack2bf(s[qb][8 * ks + 2], s[qb][8 * ks + 3]),
+                           pack2bf(s[qb][8 * ks + 4], s[qb][8 * ks + 5]), pack2bf(s[qb][8 * ks + 6], s[qb][8 * ks + 7])};
+    }
+  };
+  auto interleave = [&]() {              // 16 x { 1 MFMA, 2 LDS reads, 7 VALU }: the scheduler pipelines the block this way
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+    }
+  };
   f32x16 sA[2], sB[2];
   u32x4 pA[2][2], pB[2][2];
+  float muA[2], muB[2];
   for (int t = 0; t < ntiles; ++t) {
-    if (PIPE == 0) {                    // plain order
+    if (PIPE == 2) {
+      qk_half(0, sA);
+      max_half(sA, muA);
+      __builtin_amdgcn_sched_barrier(0);
+      qk_half(1, sB);
+      exp_half(sA, muA, pA);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      max_half(sB, muB);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(0, pA);
+      exp_half(sB, muB, pB);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(1, pB);
+    } else if (PIPE == 0) {             // plain order
       qk_half(0, sA); softmax_half(sA, pA); pv_half(0, pA);
       qk_half(1, sB); softmax_half(sB, pB); pv_half(1, pB);
     } else {                            // source order of the pipelined schedule: the compiler may overlap neighbours
@@ -151,6 +213,6 @@ extern "C" int attn_proto_launch(const void* q, const void* k, const void* v, vo
   dim3 grid(rows / 256), block(256);
 #define GO(P, Q) { (void)hipFuncSetAttribute((const void*)attn_proto<P, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 0); \
     hipLaunchKernelGGL((attn_proto<P, Q>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc); }
-  if (pipe == 0) GO(0, false) else if (pipe == 1) GO(1, false) else if (pipe == 2) GO(0, true) else GO(1, true)
+  if (pipe == 0) GO(0, false) else if (pipe == 1) GO(1, false) else if (pipe == 2) GO(0, true) else if (pipe == 3) GO(1, true) else GO(2, true)
   return (int)hipGetLastError();
 }

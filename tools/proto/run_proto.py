@@ -14,7 +14,7 @@ v = torch.randn(64, d, device=dev, generator=g).to(torch.bfloat16)
 o = torch.empty(rows, d, device=dev, dtype=torch.bfloat16)
 sc = d ** -0.5 * 1.4426950408889634
 st = torch.cuda.current_stream().cuda_stream
-for pipe in (0, 1, 2, 3):
+for pipe in (0, 1, 2, 3, 4):
     for _ in range(3):
         lib.attn_proto_launch(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), rows, ntiles, sc, pipe, st)
     torch.cuda.synchronize()
