@@ -66,6 +66,13 @@ IVL_API const char* ivl_last_error(void);
 IVL_API int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
                           void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
                           int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream);
+/* The same rule on IEEE-half activations (q, k, v, beta, o fp16; g fp32; the state in its own dtype): fla's operators take fp16 as
+ * well as bf16 (fla:ops/gated_delta_rule/chunk.py:352 refuses fp32 only).  The package serves BOTH GDN operators with it when
+ * handed fp16 tensors -- fp32 arithmetic on the fp16 inputs, token by token, whatever T: the function the chunkwise form
+ * evaluates, without that form's intermediate roundings (the MFMA kernels of the chunk path are bf16 / e4m3 only). */
+IVL_API int ivl_gdn_recurrent_f16_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                              void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                              int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gated DeltaNet, chunkwise form (chunk = 64 tokens).

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "ivl_linear_swiglu_small_m_fwd", "ivl_gdn_decode_step_fwd", "ivl_gdn_chunk_fused_fwd", "ivl_rope_tables_fwd",
     "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd", "ivl_norm_linear_small_m_fwd",
     "ivl_gdn_sync_status", "ivl_gdn_sync_reset", "ivl_gdn_resident_blocks",
-    "ivl_short_conv_bias_fwd", "ivl_rmsnorm_swish_gate_res_fwd",
+    "ivl_short_conv_bias_fwd", "ivl_rmsnorm_swish_gate_res_fwd", "ivl_gdn_recurrent_f16_fwd",
 )
 
 
@@ -95,6 +95,8 @@ def load(path: str = None) -> ctypes.CDLL:
         lib.ivl_short_conv_bias_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         lib.ivl_rmsnorm_swish_gate_res_fwd.restype = i
         lib.ivl_rmsnorm_swish_gate_res_fwd.argtypes = [vp, vp, vp, vp, i, vp, i, vp, i, i, f, vp]
+        lib.ivl_gdn_recurrent_f16_fwd.restype = i
+        lib.ivl_gdn_recurrent_f16_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, i, i, f, i, vp]
     lib.ivl_rope_tables_fwd.restype = i
     lib.ivl_rope_tables_fwd.argtypes = [vp, vp, vp, vp, i, i, f, vp]
     lib.ivl_vision_attn_workspace_bytes.restype = sz

@@ -15,6 +15,19 @@ constexpr int REC_BV = 32;   // state columns per workgroup
 constexpr int REC_TB = 32;   // tokens staged per block
 constexpr int REC_K = 128;
 
+// F16: the activations (q, k, v, beta in; o out; the l2norm's rounding point) are IEEE half instead of bf16 -- fla's operators take
+// either (chunk.py:352 refuses fp32 only); everything else (fp32 arithmetic, the state's own dtype) is the same code.
+template <bool F16> struct Act {
+  static __device__ __forceinline__ float lo(unsigned int w) { return F16 ? h2f_bits((unsigned short)(w & 0xffffu)) : bflo(w); }
+  static __device__ __forceinline__ float hi(unsigned int w) { return F16 ? h2f_bits((unsigned short)(w >> 16)) : bfhi(w); }
+  static __device__ __forceinline__ float from(bf16_t x) { return F16 ? h2f_bits(x) : bf2f(x); }
+  static __device__ __forceinline__ bf16_t to(float f) {
+    if constexpr (F16) { const _Float16 hh = (_Float16)f; return __builtin_bit_cast(unsigned short, hh); }
+    else return f2bf(f);
+  }
+  static __device__ __forceinline__ float round(float f) { return from(to(f)); }
+};
+template <bool F16>
 __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const float* __restrict__ g, const bf16_t* __restrict__ beta, bf16_t* __restrict__ o,
@@ -63,22 +76,22 @@ __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
       const size_t tok = ((size_t)b * T + (t0 + tt)) * H + h;
       const unsigned int qw = *(const unsigned int*)(q + tok * REC_K + 2 * lane);
       const unsigned int kw = *(const unsigned int*)(k + tok * REC_K + 2 * lane);
-      float q0 = bflo(qw), q1 = bfhi(qw), k0 = bflo(kw), k1 = bfhi(kw);
+      float q0 = Act<F16>::lo(qw), q1 = Act<F16>::hi(qw), k0 = Act<F16>::lo(kw), k1 = Act<F16>::hi(kw);
       if (l2norm) {
         const float qs = wave_sum(q0 * q0 + q1 * q1);
         const float ks = wave_sum(k0 * k0 + k1 * k1);
         const float rq = 1.0f / sqrtf(qs + 1e-6f), rk = 1.0f / sqrtf(ks + 1e-6f);
-        q0 = bf_round(q0 * rq); q1 = bf_round(q1 * rq);     // fla l2norm_fwd writes bf16
-        k0 = bf_round(k0 * rk); k1 = bf_round(k1 * rk);
+        q0 = Act<F16>::round(q0 * rq); q1 = Act<F16>::round(q1 * rq);     // fla l2norm_fwd writes the activation dtype
+        k0 = Act<F16>::round(k0 * rk); k1 = Act<F16>::round(k1 * rk);
       }
       q0 *= scale; q1 *= scale;
       const float kq = wave_sum(k0 * q0 + k1 * q1);
       s_q[tt][2 * lane] = q0; s_q[tt][2 * lane + 1] = q1;
       s_k[tt][2 * lane] = k0; s_k[tt][2 * lane + 1] = k1;
-      if (lane < REC_BV) s_v[tt][lane] = bf2f(v[tok * V + v0 + lane]);
+      if (lane < REC_BV) s_v[tt][lane] = Act<F16>::from(v[tok * V + v0 + lane]);
       if (lane == 0) {
         s_eg[tt] = __expf(g[tok]);
-        s_beta[tt] = bf2f(beta[tok]);
+        s_beta[tt] = Act<F16>::from(beta[tok]);
         s_kq[tt] = kq;
       }
     }
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
       for (int r = 0; r < 16; ++r) S[r] = fmaf(kk[r], delta, S[r]);
       if (rg == 0) {
         const size_t tok = ((size_t)b * T + (t0 + tt)) * H + h;
-        o[tok * V + v0 + c] = f2bf(fmaf(delta, s_kq[tt], oq));
+        o[tok * V + v0 + c] = Act<F16>::to(fmaf(delta, s_kq[tt], oq));
       }
       par ^= 1;
     }
@@ -138,18 +151,35 @@ __global__ __launch_bounds__(256) void gdn_recurrent_kernel(
 
 using namespace ivl;
 
+template <bool F16>
+static int gdn_recurrent_launch(const char* who, const void* q, const void* k, const void* v, const float* g, const void* beta,
+                                void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                                int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream);
+
 extern "C" int ivl_gdn_recurrent_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
                                      void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
                                      int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream) {
-  IVL_REQUIRE(q && k && v && g && beta && o, IVL_ERR_INVALID_ARG, "ivl_gdn_recurrent_fwd: NULL pointer");
-  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "ivl_gdn_recurrent_fwd: B,T,H must be positive (%d,%d,%d)", B, T, H);
-  IVL_REQUIRE(K == REC_K, IVL_ERR_UNSUPPORTED, "ivl_gdn_recurrent_fwd: K=%d unsupported (built for 128)", K);
-  IVL_REQUIRE(V > 0 && V % REC_BV == 0, IVL_ERR_UNSUPPORTED, "ivl_gdn_recurrent_fwd: V=%d must be a multiple of %d", V, REC_BV);
+  return gdn_recurrent_launch<false>("ivl_gdn_recurrent_fwd", q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, K, V, scale, use_qk_l2norm, stream);
+}
+extern "C" int ivl_gdn_recurrent_f16_fwd(const void* q, const void* k, const void* v, const float* g, const void* beta,
+                                         void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                                         int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream) {
+  return gdn_recurrent_launch<true>("ivl_gdn_recurrent_f16_fwd", q, k, v, g, beta, o, h0, h0_dtype, ht, ht_dtype, B, T, H, K, V, scale, use_qk_l2norm, stream);
+}
+
+template <bool F16>
+static int gdn_recurrent_launch(const char* who, const void* q, const void* k, const void* v, const float* g, const void* beta,
+                                void* o, const void* h0, int h0_dtype, void* ht, int ht_dtype,
+                                int B, int T, int H, int K, int V, float scale, int use_qk_l2norm, void* stream) {
+  IVL_REQUIRE(q && k && v && g && beta && o, IVL_ERR_INVALID_ARG, "%s: NULL pointer", who);
+  IVL_REQUIRE(B > 0 && T > 0 && H > 0, IVL_ERR_INVALID_ARG, "%s: B,T,H must be positive (%d,%d,%d)", who, B, T, H);
+  IVL_REQUIRE(K == REC_K, IVL_ERR_UNSUPPORTED, "%s: K=%d unsupported (built for 128)", who, K);
+  IVL_REQUIRE(V > 0 && V % REC_BV == 0, IVL_ERR_UNSUPPORTED, "%s: V=%d must be a multiple of %d", who, V, REC_BV);
   IVL_REQUIRE((h0 == nullptr || h0_dtype == IVL_F32 || h0_dtype == IVL_BF16) &&
               (ht == nullptr || ht_dtype == IVL_F32 || ht_dtype == IVL_BF16),
-              IVL_ERR_INVALID_ARG, "ivl_gdn_recurrent_fwd: state dtype must be IVL_F32 or IVL_BF16");
-  hipLaunchKernelGGL(gdn_recurrent_kernel, dim3(V / REC_BV, B * H), dim3(256), 0, (hipStream_t)stream,
+              IVL_ERR_INVALID_ARG, "%s: state dtype must be IVL_F32 or IVL_BF16", who);
+  hipLaunchKernelGGL(gdn_recurrent_kernel<F16>, dim3(V / REC_BV, B * H), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, g, (const bf16_t*)beta, (bf16_t*)o,
                      h0, h0_dtype, ht, ht_dtype, T, H, V, scale, use_qk_l2norm);
-  return check_launch("ivl_gdn_recurrent_fwd");
+  return check_launch(who);
 }

@@ -98,8 +98,8 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
     _need_gpu(q, k, v, g, beta, initial_state)
     assert q.dtype == k.dtype == v.dtype, "q, k, v must share a dtype"
     assert len(beta.shape) == 3, "beta must be of shape [B, T, H]"                       # chunk.py:353
-    if q.dtype != torch.bfloat16:
-        raise ValueError(f"infinitevl_amd GDN kernels are built for bf16 activations, got {q.dtype}")
+    if q.dtype not in (torch.bfloat16, torch.float16):                                    # chunk.py:352 refuses fp32 only
+        raise ValueError(f"infinitevl_amd GDN kernels take bf16 (or fp16) activations, got {q.dtype}")
     B, T, H, K = k.shape
     V = v.shape[-1]
     NS = B                                                                                # number of sequences = number of states
@@ -125,8 +125,8 @@ def _gdn_common(q, k, v, g, beta, scale, initial_state, output_final_state, cu_s
     if g.dtype != torch.float32:
         g = g.float()
     beta = beta.contiguous()
-    if beta.dtype != torch.bfloat16:
-        beta = beta.to(torch.bfloat16)
+    if beta.dtype != q.dtype:
+        beta = beta.to(q.dtype)
     if initial_state is not None:
         if initial_state.dtype not in _DT_CODE:
             initial_state = initial_state.float()
@@ -195,8 +195,10 @@ def fused_recurrent_gated_delta_rule(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
     lib = _lib.load()
 
+    rec_fwd = lib.ivl_gdn_recurrent_f16_fwd if q.dtype == torch.float16 else lib.ivl_gdn_recurrent_fwd
+
     def entry(q_, k_, v_, g_, b_, o_, hi, ho, Tn, H_, K_, V_, sc, l2):
-        _lib.check(lib.ivl_gdn_recurrent_fwd(
+        _lib.check(rec_fwd(
             _p(q_), _p(k_), _p(v_), _p(g_), _p(b_), _p(o_),
             _p(hi), _DT_CODE[hi.dtype] if hi is not None else IVL_F32,
             _p(ho), _DT_CODE[ho.dtype] if ho is not None else IVL_F32,
@@ -221,6 +223,17 @@ def chunk_gated_delta_rule(
         q, k, v, g, beta = _from_head_first(q, k, v, g, beta, cu_seqlens)
     q, k, v, g, beta, scale, h0, ht, o, (B, T, H, K, V) = _gdn_common(
         q, k, v, g, beta, scale, initial_state, output_final_state, cu_seqlens, final_state_out)
+    if q.dtype == torch.float16:
+        # IEEE-half activations (accepted by fla, chunk.py:352; never used by InfiniteVL): the MFMA kernels of the chunk path are
+        # bf16 / e4m3 only, so the call runs on the token-recurrent kernel's fp16 instance -- the same function, fp32 arithmetic on
+        # the fp16 inputs without the chunk form's intermediate roundings (within the operator's tolerance of the reference's fp16
+        # chunk result: fixture gdn_chunk_T160_fp16)
+        if mma_code(mma_dtype) != IVL_BF16:
+            raise ValueError("mma_dtype applies to bf16 activations only")
+        o, ht = fused_recurrent_gated_delta_rule(q, k, v, g, beta, scale=scale, initial_state=initial_state,
+                                                 output_final_state=output_final_state, cu_seqlens=cu_seqlens,
+                                                 use_qk_l2norm_in_kernel=use_qk_l2norm_in_kernel, final_state_out=final_state_out)
+        return (o.transpose(1, 2) if head_first else o), ht
     lib = _lib.load()
     segs = _varlen_segments(cu_seqlens, T) if cu_seqlens is not None else None
     Tmax = max([b_ - a for a, b_ in segs] + [1]) if segs is not None else T

@@ -146,6 +146,29 @@ def test_gdn_chunk_equals_recurrent_kernel_at_full_width():
     assert rms_rel(o2.float().cpu(), o1.float().cpu()) < 5e-3 and rms_rel(s2.cpu(), s1.cpu()) < 5e-3
 
 
+def test_gdn_fp16_activations_reference_vectors():
+    """IEEE-half activations (fla accepts them: chunk.py:352 refuses fp32 only): both operators on fp16 tensors against the
+    reference's own fp16 chunk result (fixture gdn_chunk_T160_fp16, produced through fla's public wrapper) -- fp16 in, fp16 out,
+    fp32 state; <= 5e-3 like every bf16-I/O kernel (the package evaluates the rule token by token in fp32 on the fp16 inputs: no
+    intermediate roundings, so it sits at the fp16 noise floor of the reference's chunk form) -- and against the oracle's exact
+    recurrent rule on the same fp16-valued inputs."""
+    from infinitevl_amd import ops
+    z = load_golden("gdn_chunk_T160_fp16")
+    q, k, v, beta = (z[n].to(DEV, torch.float16) for n in ("q_f16", "k_f16", "v_f16", "beta_f16"))
+    g, h0 = z["g"].to(DEV), z["h0"].to(DEV)
+    o_ex, s_ex = ogdn.gdn_recurrent(z["q_f16"].float(), z["k_f16"].float(), z["v_f16"].float(), z["g"], z["beta_f16"].float(), initial_state=z["h0"],
+                                    qk_round_dtype=torch.float16)
+    for fn in (ops.chunk_gated_delta_rule, ops.fused_recurrent_gated_delta_rule):
+        o, ht = fn(q, k, v, g, beta, initial_state=h0, output_final_state=True, use_qk_l2norm_in_kernel=True)
+        assert o.dtype == torch.float16 and ht.dtype == torch.float32
+        assert rms_rel(z["o"], o.float().cpu()) < 5e-3 and rms_rel(z["ht"], ht.cpu()) < 5e-3, fn.__name__
+        assert rms_rel(o_ex, o.float().cpu()) < 1e-3 and rms_rel(s_ex, ht.cpu()) < 1e-4, fn.__name__
+    with pytest.raises(ValueError):
+        ops.chunk_gated_delta_rule(q, k, v, g, beta, mma_dtype="fp8_e4m3")
+    with pytest.raises(ValueError):
+        ops.chunk_gated_delta_rule(q.float(), k.float(), v.float(), g, beta.float())          # fp32 stays refused (chunk.py:352)
+
+
 def test_gdn_varlen_reference_vectors():
     """cu_seqlens inputs of both GDN operators against the reference's own outputs (4 flattened sequences of 70 / 100 / 1 / 79
     tokens, one initial state each) and, bit for bit, against the same sequences as separate calls; fla's argument checks."""
