@@ -16,6 +16,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import threading
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -257,6 +258,13 @@ def chunk_gated_delta_rule(
 
 
 _GDN_SYNC: Dict[Tuple[int, object], torch.Tensor] = {}
+_GDN_SYNC_OWNED = weakref.WeakValueDictionary()      # areas handed out by new_gdn_sync_area: they die with their owner (a GraphedStep)
+
+
+def _all_gdn_sync_areas(dev: int):
+    areas = [a for (d, _), a in list(_GDN_SYNC.items()) if d == dev]
+    areas += [a for (d, _), a in list(_GDN_SYNC_OWNED.items()) if d == dev]
+    return areas
 _GDN_SYNC_SCOPE = threading.local()      # .areas: {device index: area} inside `with gdn_sync_scope(area)`
 _GDN_SINGLE_LAUNCH = True      # tests switch it off to compare the single-launch form with the two-launch form
 
@@ -267,7 +275,7 @@ def new_gdn_sync_area(device) -> torch.Tensor:
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("a GDN sync area cannot be created during hipGraph capture; create it (or run a warm-up step) first")
     area = torch.zeros(_lib.IVL_GDN_SYNC_BYTES, dtype=torch.uint8, device=device)
-    _GDN_SYNC[(area.device.index, id(area))] = area          # known to gdn_sync_check(deep=True) / gdn_sync_reset
+    _GDN_SYNC_OWNED[(area.device.index, id(area))] = area    # known to gdn_sync_check(deep=True) / gdn_sync_reset while its owner lives
     return area
 
 
@@ -336,9 +344,8 @@ def gdn_sync_check(device=None, *, deep: bool = False) -> None:
         _lib.check(lib.ivl_gdn_sync_status(None, None))
         if deep:
             dev = device.index if device.index is not None else torch.cuda.current_device()
-            for (d, _), area in list(_GDN_SYNC.items()):
-                if d == dev:
-                    _lib.check(lib.ivl_gdn_sync_status(_p(area), _stream(area)))
+            for area in _all_gdn_sync_areas(dev):
+                _lib.check(lib.ivl_gdn_sync_status(_p(area), _stream(area)))
 
 
 def gdn_sync_reset(device=None) -> None:
@@ -349,9 +356,8 @@ def gdn_sync_reset(device=None) -> None:
     lib = _lib.load()
     with torch.cuda.device(device):
         torch.cuda.synchronize(device)
-        for (d, _), area in list(_GDN_SYNC.items()):
-            if d == dev:
-                _lib.check(lib.ivl_gdn_sync_reset(_p(area), _stream(area)))
+        for area in _all_gdn_sync_areas(dev):
+            _lib.check(lib.ivl_gdn_sync_reset(_p(area), _stream(area)))
         torch.cuda.synchronize(device)
 
 

@@ -1902,7 +1902,6 @@ def test_gdn_single_launch_reports_a_wait_that_runs_out(T, chunk):
     finally:
         torch.cuda.synchronize()
         ops.gdn_sync_reset(DEV)
-        ops._GDN_SYNC.pop((area.device.index, id(area)), None)
 
 
 def test_graphed_step_surfaces_a_failed_wait_and_recovers():

@@ -97,7 +97,7 @@ def main() -> int:
         ops.gdn_sync_check(dev, deep=True)
     except Exception as e:  # noqa: BLE001
         err = f" sync error: {e}"
-    leftover = sum(int(v.view(torch.int32).abs().sum()) for v in ops._GDN_SYNC.values())
+    leftover = sum(int(v.view(torch.int32).abs().sum()) for v in ops._all_gdn_sync_areas(0))
     ok = bad == 0 and not err and leftover == 0
     print(f"GDN_SYNC_STRESS {'PASS' if ok else 'FAIL'} pid={os.getpid()} calls={calls} mismatches={bad} flags_left={leftover}{err}",
           flush=True)
