@@ -593,51 +593,79 @@ def main():
     #      gloo debug backend).  Checked on the last rank against its own single-rank run of the same call sequence.
     sp = None
     if world > 1 and not args.no_sp:
-      try:                                   # (never lose the headline line over the extra leg: an exception is recorded instead)
+        # Every stage that can fail on ONE rank (allocations, the last rank's single-rank reference run) ends in an exchange of
+        # an ok flag (all_reduce MIN) BEFORE the next collective, so a rank that raised does not leave the others blocked in a
+        # barrier / broadcast: all ranks then skip the rest of the leg and the error is recorded.  The headline above is
+        # already measured; the leg never raises.
+        def all_ok(ok: bool) -> bool:
+            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MIN)
+            return bool(int(t_.item()))
+
         Ts = args.sp_tokens
-        gsp = torch.Generator(device=device).manual_seed(4242)           # the same sequence on every rank
-        xs_all = (torch.randn(1, world * Ts, cfg.hidden_size, device=device, generator=gsp) * 0.02).to(torch.bfloat16)
+        err, xs_all, cache_sp, lg_sp, sp_ms = None, None, None, None, []
         first, last_tok = ivd.segment_bounds(world * Ts, rank, world)
-        cache_sp = model.allocate_inference_cache(1)
-        sp_ms = []
-        with torch.no_grad():
-            for rep in range(2):                                          # rep 0: communicator set-up and warm-up, rep 1: timed
-                cache_sp.reset()
-                ivd.barrier()
-                torch.cuda.synchronize()
-                tA = time.perf_counter()
-                _, lg_sp = ivd.sequence_parallel_prefill(model, xs_all[:, first:last_tok], cache_sp, first, rank, world, logits_to_keep=1)
-                torch.cuda.synchronize()
-                ivd.barrier()
-                sp_ms.append(ivd.max_over_ranks((time.perf_counter() - tA) * 1e3, device))
-            check = {"equal": None, "max_abs_diff": None}
+        try:
+            gsp = torch.Generator(device=device).manual_seed(4242)       # the same sequence on every rank
+            xs_all = (torch.randn(1, world * Ts, cfg.hidden_size, device=device, generator=gsp) * 0.02).to(torch.bfloat16)
+            cache_sp = model.allocate_inference_cache(1)
+        except Exception as e:               # noqa: BLE001
+            err = f"setup: {type(e).__name__}: {e}"
+        if not all_ok(err is None):
+            err = err or "setup failed on another rank"
+        else:
+            try:
+                with torch.no_grad():
+                    for rep in range(2):                                  # rep 0: communicator set-up and warm-up, rep 1: timed
+                        cache_sp.reset()
+                        ivd.barrier()
+                        torch.cuda.synchronize()
+                        tA = time.perf_counter()
+                        _, lg_sp = ivd.sequence_parallel_prefill(model, xs_all[:, first:last_tok], cache_sp, first, rank, world, logits_to_keep=1)
+                        torch.cuda.synchronize()
+                        ivd.barrier()
+                        sp_ms.append(ivd.max_over_ranks((time.perf_counter() - tA) * 1e3, device))
+            except Exception as e:           # noqa: BLE001   (a failure INSIDE the hand-off is a communicator failure: nothing to exchange)
+                err = f"prefill: {type(e).__name__}: {e}"
+        check = {"equal": None, "max_abs_diff": None}
+        if err is None:
             if rank == world - 1:                                         # the single-rank run of the same call sequence
-                cache_1 = model.allocate_inference_cache(1)
-                tB = time.perf_counter()
-                for r_ in range(world):
-                    f_, l_ = ivd.segment_bounds(world * Ts, r_, world)
-                    pos_ = torch.arange(f_, l_, device=device)[None, None, :].expand(3, 1, l_ - f_).contiguous()
-                    _, lg_1 = model(inputs_embeds=xs_all[:, f_:l_], position_ids=pos_, past_key_values=cache_1, logits_to_keep=1)
-                torch.cuda.synchronize()
-                one_rank_ms = (time.perf_counter() - tB) * 1e3
-                check = {"equal": bool(torch.equal(lg_sp, lg_1)), "max_abs_diff": float((lg_sp.float() - lg_1.float()).abs().max()),
-                         "single_rank_ms": one_rank_ms, "finite": bool(torch.isfinite(lg_sp.float()).all())}
-                del cache_1
-            box = [check]
-            torch.distributed.broadcast_object_list(box, src=world - 1)
-            check = box[0]
-        backend = torch.distributed.get_backend()
-        sp = {"workload": f"sequence-parallel prefill of ONE {world * Ts}-token sequence over {world} ranks ({Ts} tokens per rank), "
-                          f"per-layer carried-state hand-off rank r -> r + 1 (SURVEY.md 8f-4; the reference has no such path)",
-              "tokens": world * Ts, "ms": sp_ms[-1], "ms_first_run_with_setup": sp_ms[0], "tok_s": world * Ts / (sp_ms[-1] * 1e-3),
-              "backend": backend, "device_p2p": backend == "nccl",
-              "transport": "device tensors, batch_isend_irecv (RCCL over xGMI)" if backend == "nccl" else "host-staged (gloo debug backend)",
-              "last_token_logits_equal_single_rank_run": check["equal"], "max_abs_diff": check["max_abs_diff"],
-              "single_rank_ms_same_calls": check.get("single_rank_ms"), "speedup_vs_single_rank": (check["single_rank_ms"] / sp_ms[-1]) if check.get("single_rank_ms") else None,
-              "logits_finite": check.get("finite")}
+                try:
+                    with torch.no_grad():
+                        cache_1 = model.allocate_inference_cache(1)
+                        tB = time.perf_counter()
+                        for r_ in range(world):
+                            f_, l_ = ivd.segment_bounds(world * Ts, r_, world)
+                            pos_ = torch.arange(f_, l_, device=device)[None, None, :].expand(3, 1, l_ - f_).contiguous()
+                            _, lg_1 = model(inputs_embeds=xs_all[:, f_:l_], position_ids=pos_, past_key_values=cache_1, logits_to_keep=1)
+                        torch.cuda.synchronize()
+                        one_rank_ms = (time.perf_counter() - tB) * 1e3
+                        check = {"equal": bool(torch.equal(lg_sp, lg_1)), "max_abs_diff": float((lg_sp.float() - lg_1.float()).abs().max()),
+                                 "single_rank_ms": one_rank_ms, "finite": bool(torch.isfinite(lg_sp.float()).all())}
+                        del cache_1
+                except Exception as e:       # noqa: BLE001
+                    err = f"single-rank reference run: {type(e).__name__}: {e}"
+            if not all_ok(err is None):
+                err = err or "the single-rank reference run failed on the last rank"
+            else:
+                box = [check]
+                torch.distributed.broadcast_object_list(box, src=world - 1)
+                check = box[0]
+        if err is not None:
+            sp = {"error": err, "failed": True}
+        else:
+            backend = torch.distributed.get_backend()
+            sp = {"workload": f"sequence-parallel prefill of ONE {world * Ts}-token sequence over {world} ranks ({Ts} tokens per rank), "
+                              f"per-layer carried-state hand-off rank r -> r + 1 (SURVEY.md 8f-4; the reference has no such path)",
+                  "tokens": world * Ts, "ms": sp_ms[-1], "ms_first_run_with_setup": sp_ms[0], "tok_s": world * Ts / (sp_ms[-1] * 1e-3),
+                  "backend": backend, "device_p2p": backend == "nccl",
+                  "transport": "device tensors, batch_isend_irecv (RCCL over xGMI)" if backend == "nccl" else "host-staged (gloo debug backend)",
+                  "last_token_logits_equal_single_rank_run": check["equal"], "max_abs_diff": check["max_abs_diff"],
+                  # the same kernels run the same call sequence on both sides: anything but bit-equality is a failure of the hand-off
+                  "failed": check["equal"] is not True,
+                  "single_rank_ms_same_calls": check.get("single_rank_ms"), "speedup_vs_single_rank": (check["single_rank_ms"] / sp_ms[-1]) if check.get("single_rank_ms") else None,
+                  "logits_finite": check.get("finite")}
         del cache_sp, xs_all
-      except Exception as e:                 # noqa: BLE001
-        sp = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- fp8 leg (rank 0, reported beside the headline, never mixed into `value`): BASELINE.json configs[4] -- the same
     #      steady-state streaming step and decode step with e4m3 operands in the GDN chunk scan / SWA decode step

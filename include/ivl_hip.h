@@ -14,8 +14,10 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
  *     the library never allocates, frees, synchronises or branches on device data on the
  *     host, so every call is hipGraph-capturable (SURVEY.md section 8b "Threading / streams").
- *     (One exception: the first GDN chunk call on a device pins 64 bytes of host memory for the
- *     status word of ivl_gdn_sync_status; ivl_gdn_sync_status(sync != NULL) is the one blocking call.)
+ *     (One exception, ownership: the first GDN chunk call on a device makes ONE hipHostMalloc of 512 bytes of pinned,
+ *     device-mapped host memory -- 64 status slots of two words for ivl_gdn_sync_status -- owned by the library and kept
+ *     for the life of the process; if it fails the library runs without it.  ivl_gdn_sync_status(sync != NULL) is the
+ *     one blocking call.)
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - layouts are the reference's time-major ones: q,k [B,T,H,K], v,o [B,T,H,V],
  *     g,beta [B,T,H], recurrent state [B,H,K,V]; bf16 activations, fp32 g.
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 8
+#define IVL_ABI_VERSION 9
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -118,8 +120,11 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  *   the two-launch form.  Contract of the in-launch waits (csrc/gdn_chunk.hip, scan_wait_records): a workgroup only waits for
  *   workgroups with lower block ids; every wait is bounded; a wait that runs out raises a sticky error word in the area and in
  *   a host-visible status word, and the waiting workgroup stores NO output / state computed from records it has not seen.
- *   After that this entry point returns IVL_ERR_SYNC for every call with a sync area on that device (and launches nothing)
- *   until ivl_gdn_sync_reset; workgroups of launches already queued (a hipGraph) stop at once when they find the area failed.
+ *   After that this entry point returns IVL_ERR_SYNC for every call with THAT sync area (and launches nothing) until
+ *   ivl_gdn_sync_reset of the area; calls with other areas -- other streams, other graphs -- go on (an area reports into the
+ *   host status slot its address hashes to, 64 slots per device: two areas that share a slot are refused together, which is
+ *   one refusal too many, never one too few); workgroups of launches already queued (a hipGraph) stop at once when they find
+ *   the area failed.
  * ------------------------------------------------------------------------------------------- */
 #define IVL_GDN_SYNC_BYTES 16384
 IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
@@ -129,15 +134,18 @@ IVL_API int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, int
                             int T, int H, int K, int V, int conv_width, float scale, int mma_dtype, void* workspace,
                             size_t workspace_bytes, void* sync, void* stream);
 /* Status of the single-launch forms on the CURRENT device: IVL_OK or IVL_ERR_SYNC (ivl_last_error(): which wait, head, chunk).
- * sync == NULL: what the kernels have reported so far through the host-visible status word -- no stream work, callable at any
- *   time, also during capture (a failure shows up once the failing kernel has run: check after a synchronisation point).
- * sync != NULL: additionally copies the area's own error word back behind `stream` and waits for it (blocking; not capturable).
- * ivl_gdn_sync_reset zeroes the area behind `stream` and clears the device's status word (also the way to initialise an area). */
+ * sync == NULL: what the kernels of ANY area have reported so far through the host-visible status slots -- no stream work,
+ *   callable at any time, also during capture (a failure shows up once the failing kernel has run: check after a
+ *   synchronisation point).
+ * sync != NULL: that area's slot, and additionally the area's own error word copied back behind `stream` (blocking; not capturable).
+ * ivl_gdn_sync_reset zeroes the area behind `stream` and clears the area's status slot (also the way to initialise an area). */
 IVL_API int ivl_gdn_sync_status(const void* sync, void* stream);
 IVL_API int ivl_gdn_sync_reset(void* sync, void* stream);
 /* The number of single-launch workgroups the library takes to be resident at once on the current device (occupancy query x CU
  * count: 256 on a whole MI355X).  override_blocks >= 0 replaces it process-wide -- 0 = always the two-launch form, a small
- * number = a partitioned / shared device; < 0 restores the query.  Returns the number in force. */
+ * number = a partitioned / shared device; < 0 restores the query; IVL_GDN_RESIDENT_QUERY changes nothing (a pure read).  Returns
+ * the number in force. */
+#define IVL_GDN_RESIDENT_QUERY (-2147483647 - 1)
 IVL_API int ivl_gdn_resident_blocks(int override_blocks);
 
 /* ---------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libivl_hip.so")
 IVL_BF16, IVL_F32, IVL_FP8_E4M3 = 0, 2, 3
 IVL_OK = 0
 IVL_GDN_SYNC_BYTES = 16384
+IVL_GDN_RESIDENT_QUERY = -2147483648      # ivl_gdn_resident_blocks: a pure read
 IVL_ERR_INVALID_ARG, IVL_ERR_UNSUPPORTED, IVL_ERR_WORKSPACE, IVL_ERR_LAUNCH, IVL_ERR_SYNC = -1, -2, -3, -4, -5
 
 EXPORTED_SYMBOLS = (
@@ -142,7 +143,7 @@ def load(path: str = None) -> ctypes.CDLL:
     _lib = lib
     # the one environment switch, on the Python side: IVL_GDN_RESIDENT_BLOCKS=0 forces the two-launch form of the fused GDN call
     env = os.environ.get("IVL_GDN_RESIDENT_BLOCKS", "")
-    if env.strip():
+    if env.strip() and hasattr(lib, "ivl_gdn_resident_blocks"):
         lib.ivl_gdn_resident_blocks(int(env))
     return lib
 

@@ -1136,7 +1136,12 @@ __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, in
     const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != want);
     if (bad == 0ull) return true;
-    if (bad >> 63) return false;                                           // the area has failed before: no use waiting
+    if (bad >> 63) {                                                       // the area has failed before: no use waiting
+      // ... and the host hears of it again: ivl_gdn_sync_reset of ANOTHER area that shares this area's status slot (slots are
+      // assigned by address hash) has cleared the slot while this area is still failed
+      if (lane == 63 && sy.host_err != nullptr) __hip_atomic_store(sy.host_err, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
     __builtin_amdgcn_s_sleep(4);
   }
   if (lane == 0) sync_fail(sy, SYNC_E_START, bh, 0);
@@ -1166,11 +1171,7 @@ __device__ __forceinline__ void scan_loader(const unsigned char* ws_bh, int nt_s
   // NCW = 4: the V waves load their rows / Tu / beta themselves, loaders 2, 3 warm the L2 for them (one touch per chunk)
   // NCW = 2: the loaders fetch the value tile, beta (with H2: the "T batch") and Tu (with H1: the "M batch") for real
   constexpr bool VD = NCW == 2;
-#ifdef IVL_AB_NO_SC1
-  constexpr bool DEV = false;                                               // (developer A/B only)
-#else
   constexpr bool DEV = SYNC != 0;                                           // the records come from workgroups of this launch: sc1 loads
-#endif
   constexpr int TW = VD ? 0 : (L == 2 || L == 3 ? L : 0);                   // what this loader touches (2: value rows, 3: Tu / beta)
   constexpr int NT = TW != 0 ? 1 : 0;                                       // touch instructions per chunk
   constexpr int NVB = VD ? vt_instrs<L>() + (L == 3 ? 1 : 0) : 0;           // value tile + beta instructions per chunk
@@ -2145,8 +2146,15 @@ static void scan_set_attr() {
 }
 static int g_cu_count[64];
 static int g_resident[64][2];                       // [device][F8]: workgroups of the single-launch kernels that can be resident at once
-static unsigned int* g_host_status[64];             // [device]: two words of pinned host memory the kernels report a failed wait in
+// [device]: SYNC_STATUS_SLOTS x two words (code, where) of pinned host memory the kernels report a failed wait in.  A sync area
+// reports into the slot its ADDRESS hashes to, so one area's failure refuses further launches on that area (and on the rare area
+// that shares its slot: a refusal too many, never one too few), not on every stream and graph of the device.
+constexpr int SYNC_STATUS_SLOTS = 64;
+static unsigned int* g_host_status[64];
 static unsigned int* g_host_status_dev[64];         // ... as the device addresses them
+static inline int status_slot(const void* sync) {
+  return (int)((((unsigned int)((unsigned long long)(size_t)sync >> 8)) * 0x9E3779B1u) >> 26);       // 0 .. 63
+}
 static int device_index() {
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -2195,12 +2203,12 @@ static void gdn_chunk_init_device() {
     auto min3 = [](int a, int b, int c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
     g_resident[dev][0] = min3(single_occupancy<false, 0>(lds16, cus), single_occupancy<false, 1>(lds16, cus), single_occupancy<false, 2>(lds16, cus));
     g_resident[dev][1] = min3(single_occupancy<true, 0>(lds8, cus), single_occupancy<true, 1>(lds8, cus), single_occupancy<true, 2>(lds8, cus));
-    // the status word: 64 bytes of pinned, device-mapped host memory for the life of the process (the one thing the library
+    // the status slots: 512 bytes of pinned, device-mapped host memory for the life of the process (the one thing the library
     // allocates; without it a failed wait is still recorded in the sync area and found by ivl_gdn_sync_status)
     void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hp != nullptr) {
-      __builtin_memset(hp, 0, 64);
+    if (hipHostMalloc(&hp, SYNC_STATUS_SLOTS * 8, hipHostMallocMapped) == hipSuccess && hp != nullptr) {
+      __builtin_memset(hp, 0, SYNC_STATUS_SLOTS * 8);
       if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
         g_host_status[dev] = (unsigned int*)hp;
         g_host_status_dev[dev] = (unsigned int*)dp;
@@ -2219,13 +2227,19 @@ static const char* sync_code_name(unsigned int code) {
     default: return "unknown code";
   }
 }
-// the host-visible status of the current device: 0 = healthy
-static unsigned int host_status(unsigned int* where) {
+// the host-visible status of the current device: 0 = healthy.  sync != NULL: of that area's slot; NULL: the first failed slot
+static unsigned int host_status(const void* sync, unsigned int* where) {
   const unsigned int* hs = g_host_status[device_index()];
   if (hs == nullptr) return 0u;
-  const unsigned int code = __atomic_load_n(hs, __ATOMIC_RELAXED);
-  if (where != nullptr) *where = __atomic_load_n(hs + 1, __ATOMIC_RELAXED);
-  return code;
+  const int s0 = sync != nullptr ? status_slot(sync) : 0, s1 = sync != nullptr ? s0 + 1 : SYNC_STATUS_SLOTS;
+  for (int s = s0; s < s1; ++s) {
+    const unsigned int code = __atomic_load_n(hs + 2 * s, __ATOMIC_RELAXED);
+    if (code != 0u) {
+      if (where != nullptr) *where = __atomic_load_n(hs + 2 * s + 1, __ATOMIC_RELAXED);
+      return code;
+    }
+  }
+  return 0u;
 }
 
 extern "C" size_t ivl_gdn_chunk_workspace_bytes(int B, int T, int H, int K, int V) {
@@ -2251,9 +2265,6 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   const int segc = seg_chunks(NT);
   float* carry = NT > G_SEG_CHUNKS ? (float*)(wsb + (size_t)B * H * segc * Rec<false>::STRIDE) : nullptr;
   int ncw = B * H * 4 <= 128 ? 2 : 4;          // 32-column workgroups while 64-column ones would leave half the CUs idle
-#ifdef IVL_AB_NCW
-  ncw = IVL_AB_NCW;                            // (developer A/B builds only)
-#endif
 #ifdef IVL_TRACE
   if (g_scan_ncw) ncw = g_scan_ncw;
 #endif
@@ -2281,7 +2292,7 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
   ScanSync sy;
   if (can_sync) {
     sy.flags = sync; sy.headdone = sync + SYNC_MAX_HEADS * SYNC_HEAD_WORDS; sy.kread = sy.headdone + 32; sy.err = sync + SYNC_ERR_WORD;
-    sy.host_err = g_host_status_dev[device_index()];
+    sy.host_err = g_host_status_dev[device_index()] != nullptr ? g_host_status_dev[device_index()] + 2 * status_slot(sync) : nullptr;
     sy.BH = BH; sy.nsplit = 0;
   }
   const int lds1 = scan_lds_bytes(2, F8) > P_BYTES ? scan_lds_bytes(2, F8) : P_BYTES;
@@ -2307,10 +2318,8 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
       const int hin_dt = first ? h0_dtype : IVL_F32;
       void* hout = last ? ht : (void*)carry;
       const int hout_dt = last ? ht_dtype : IVL_F32;
-#ifndef IVL_AB_NSTART
-#define IVL_AB_NSTART 5
-#endif
-      sy.nsplit = nseg < IVL_AB_NSTART ? nseg : IVL_AB_NSTART;     // starter chunks: at least what the scan's loaders request before the first chunk step
+      constexpr int NSTART = 5;                                    // (3 / 4 / 5 / 6 measured: 90.0 / 87.8 / 86.8 / 87.0 us at T = 4096)
+      sy.nsplit = nseg < NSTART ? nseg : NSTART;                   // starter chunks: at least what the scan's loaders request before the first chunk step
       int nprep = resident - 8 * BH;                               // persistent pre-pass workgroups: what the chip holds beside the scan
       if (nprep > (nseg - sy.nsplit) * BH / 2) nprep = (nseg - sy.nsplit) * BH / 2;   // (two chunk-head pairs per workgroup and round)
       hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(2 * sy.nsplit * BH + nprep + 8 * BH), dim3(LONG_THREADS), lds1, st, *pf, wsb,
@@ -2397,9 +2406,9 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
   gdn_chunk_init_device();
   if (sync != nullptr) {
     unsigned int where = 0;
-    const unsigned int code = host_status(&where);
+    const unsigned int code = host_status(sync, &where);
     IVL_REQUIRE(code == 0u, IVL_ERR_SYNC,
-                "ivl_gdn_chunk_fused_fwd: an earlier single-launch call on this device failed (code %u: %s; head %u, chunk %u): its "
+                "ivl_gdn_chunk_fused_fwd: an earlier single-launch call on this sync area failed (code %u: %s; head %u, chunk %u): its "
                 "outputs and states are incomplete. ivl_gdn_sync_reset() re-arms the sync area",
                 code, sync_code_name(code), where >> 16, where & 0xffffu);
   }
@@ -2424,7 +2433,7 @@ extern "C" int ivl_gdn_chunk_fused_fwd(const void* proj, int64_t ld, int col_q, 
 extern "C" int ivl_gdn_sync_status(const void* sync, void* stream) {
   gdn_chunk_init_device();
   unsigned int where = 0;
-  unsigned int code = host_status(&where);
+  unsigned int code = host_status(sync, &where);
   if (code == 0u && sync != nullptr) {
     unsigned int w[2] = {0u, 0u};
     hipError_t e = hipMemcpyAsync(w, (const unsigned int*)sync + SYNC_ERR_WORD, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
@@ -2437,7 +2446,7 @@ extern "C" int ivl_gdn_sync_status(const void* sync, void* stream) {
   return IVL_OK;
 }
 
-// Re-arm: zero the area (behind `stream`) and the device's host status word.  Also the way to initialise a fresh area.
+// Re-arm: zero the area (behind `stream`) and the area's host status slot.  Also the way to initialise a fresh area.
 extern "C" int ivl_gdn_sync_reset(void* sync, void* stream) {
   IVL_REQUIRE(sync != nullptr && ((size_t)sync & 15) == 0, IVL_ERR_INVALID_ARG, "ivl_gdn_sync_reset: sync area must be a 16-byte aligned device pointer");
   gdn_chunk_init_device();
@@ -2445,6 +2454,7 @@ extern "C" int ivl_gdn_sync_reset(void* sync, void* stream) {
   IVL_REQUIRE(e == hipSuccess, IVL_ERR_LAUNCH, "ivl_gdn_sync_reset: %s", hipGetErrorString(e));
   unsigned int* hs = g_host_status[device_index()];
   if (hs != nullptr) {
+    hs += 2 * status_slot(sync);
     __atomic_store_n(hs + 1, 0u, __ATOMIC_RELAXED);
     __atomic_store_n(hs, 0u, __ATOMIC_RELAXED);
   }
@@ -2453,9 +2463,10 @@ extern "C" int ivl_gdn_sync_reset(void* sync, void* stream) {
 
 // How many workgroups of the single-launch kernels the library takes to be resident at once on the current device (what gates
 // the single-launch forms).  override >= 0 replaces the occupancy-derived number process-wide (0: always two launches),
-// override < 0 restores it; returns the number in force for bf16 operands.
+// override < 0 restores it, IVL_GDN_RESIDENT_QUERY changes nothing; returns the number in force for bf16 operands.
 extern "C" int ivl_gdn_resident_blocks(int override_blocks) {
   gdn_chunk_init_device();
-  __atomic_store_n(&g_resident_override, override_blocks < 0 ? -1 : override_blocks, __ATOMIC_RELAXED);
+  if (override_blocks != IVL_GDN_RESIDENT_QUERY)
+    __atomic_store_n(&g_resident_override, override_blocks < 0 ? -1 : override_blocks, __ATOMIC_RELAXED);
   return resident_blocks(false);
 }

@@ -26,12 +26,13 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_distributed(backend: str = "nccl") -> Tuple[int, int, int]:
+def init_distributed(backend: str = "nccl", force: bool = False) -> Tuple[int, int, int]:
     """Initialise torch.distributed when WORLD_SIZE > 1 (MASTER_ADDR/PORT from the env; 127.0.0.1 on
-    one node).  Keeps HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC."""
+    one node).  Keeps HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC.  `force=True` creates the
+    process group for a single process as well (the one-GPU RCCL contact test: librccl loads, the `device_id=` init path works)."""
     rank, world, local_rank = env_world()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

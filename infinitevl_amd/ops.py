@@ -241,7 +241,7 @@ def chunk_gated_delta_rule(
     nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, Tmax, H, K, V)
     if nbytes == 0:
         raise ValueError(f"chunk_gated_delta_rule: unsupported head shape K={K}, V={V} (built for 128/256)")
-    ws = get_workspace(nbytes, q.device, "gdn")
+    _, ws = _gdn_area_and_workspace(q.device, nbytes)          # per stream / per graph, like the flag words
     mma = mma_code(mma_dtype)
 
     def entry(q_, k_, v_, g_, b_, o_, hi, ho, Tn, H_, K_, V_, sc, l2):
@@ -324,12 +324,58 @@ def _gdn_sync_area(device: torch.device) -> torch.Tensor:
     return area
 
 
-def gdn_resident_blocks(override: int = -1) -> int:
+_GDN_WS: Dict[int, list] = {}       # id(sync area) -> [records workspace, baked into a graph?, retired buffers]
+
+
+def _gdn_workspace(nbytes: int, area: torch.Tensor) -> torch.Tensor:
+    """The chunk-record workspace of the GDN calls that use sync area `area`.  Keyed like the sync area itself: two
+    calls that may run concurrently -- two streams, a replayed graph beside eager calls, two graphs -- have their own flag words
+    AND their own records; with one records buffer per device the pre-pass of one launch could overwrite records the scan of the
+    other had already seen flagged (silently wrong outputs, no IVL_ERR_SYNC).  Lives as long as the area (a GraphedStep's
+    workspace dies with it); growth rules as get_workspace: never during capture, a buffer baked into a graph is retired, not
+    freed, for as long as the area lives."""
+    key = id(area)
+    ent = _GDN_WS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None or ent[0].numel() < nbytes:
+        if capturing:
+            raise RuntimeError("the GDN workspace would have to grow during hipGraph capture; run a warm-up step first")
+        retired = ent[2] if ent is not None else []
+        grown = 0
+        if ent is not None:
+            if ent[1]:
+                retired.append(ent[0])
+            n0 = ent[0].numel()
+            grown = 2 * n0 if n0 < (256 << 20) else n0 + n0 // 4
+        else:
+            weakref.finalize(area, _GDN_WS.pop, key, None)
+        ent = [torch.empty(max(int(nbytes), grown, 1 << 20), dtype=torch.uint8, device=area.device), False, retired]
+        _GDN_WS[key] = ent
+    if capturing:
+        ent[1] = True
+    return ent[0]
+
+
+def _gdn_area_and_workspace(device: torch.device, nbytes: int):
+    """(sync area, records workspace) of a GDN chunk call on the current stream / scope.  An eager call outside any scope also
+    keeps the workspace of the device's area for scope-less CAPTURES at least as large: such a capture is preceded by a warm-up
+    of the same call -- on whatever stream -- and must find its buffers in place (they cannot be created while capturing)."""
+    area = _gdn_sync_area(device)
+    ws = _gdn_workspace(nbytes, area)
+    if not getattr(_GDN_SYNC_SCOPE, "areas", None) and not torch.cuda.is_current_stream_capturing():
+        dev = area.device.index
+        garea = _GDN_SYNC.get((dev, "graphs"))
+        if garea is not None and garea is not area:
+            _gdn_workspace(nbytes, garea)
+    return area, ws
+
+
+def gdn_resident_blocks(override: Optional[int] = None) -> int:
     """Workgroups of the single-launch GDN kernels taken to be resident at once on the current device (what gates the
-    single-launch forms: ivl_gdn_resident_blocks).  `override` >= 0 replaces the occupancy-derived number process-wide (0 =
-    always the two-launch form; the environment variable IVL_GDN_RESIDENT_BLOCKS sets it when the package is imported),
-    < 0 restores the query.  Returns the number in force."""
-    return _lib.load().ivl_gdn_resident_blocks(int(override))
+    single-launch forms: ivl_gdn_resident_blocks).  `override` None = a pure read (nothing changes); >= 0 replaces the
+    occupancy-derived number process-wide (0 = always the two-launch form; the environment variable IVL_GDN_RESIDENT_BLOCKS
+    sets it when the package is imported); < 0 restores the query.  Returns the number in force."""
+    return _lib.load().ivl_gdn_resident_blocks(_lib.IVL_GDN_RESIDENT_QUERY if override is None else int(override))
 
 
 def gdn_sync_check(device=None, *, deep: bool = False) -> None:
@@ -374,7 +420,7 @@ def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv
     nbytes = lib.ivl_gdn_chunk_workspace_bytes(B, T, H, K, V)
     if nbytes == 0:
         raise ValueError(f"gdn_chunk_fused: unsupported head shape K={K}, V={V} (built for 128/256)")
-    ws = get_workspace(nbytes, proj.device, "gdn")
+    area, ws = _gdn_area_and_workspace(proj.device, nbytes)    # records: one buffer per sync area (per stream / per graph)
     o = torch.empty(B, T, H, V, dtype=torch.bfloat16, device=proj.device)
     h0, ht = initial_state, final_state_out
     for s in (h0, ht):
@@ -387,7 +433,7 @@ def gdn_chunk_fused(proj: torch.Tensor, cols, conv_weights, conv_states_in, conv
         _p(si[0]), _p(si[1]), _p(si[2]), _p(so[0]), _p(so[1]), _p(so[2]), _p(A_log32), _p(dt_bias32), _p(o),
         _p(h0), _DT_CODE[h0.dtype] if h0 is not None else IVL_F32, _p(ht), _DT_CODE[ht.dtype] if ht is not None else IVL_F32,
         B, T, H, K, V, wq.shape[-1], float(K ** -0.5 if scale is None else scale), mma_code(mma_dtype), _p(ws), ws.numel(),
-        _p(_gdn_sync_area(proj.device)) if _GDN_SINGLE_LAUNCH else None, _stream(proj)))
+        _p(area) if _GDN_SINGLE_LAUNCH else None, _stream(proj)))
     return o
 
 
@@ -499,15 +545,17 @@ class ShortConvolution(nn.Module):
             # each other's tokens -- one call per sequence on its slice (InfiniteVL never takes this path: std:1223)
             if x.shape[0] != 1:
                 raise ValueError(f"The batch size is expected to be 1 rather than {x.shape[0]} when using `cu_seqlens`.")
+            if mask is not None:                                         # convolution.py:226-228
+                raise ValueError("`mask` and `cu_seqlens` cannot be provided at the same time")
             segs = _varlen_segments(cu_seqlens, x.shape[1])
-            if cache is not None and cache.shape[0] != len(segs):
-                raise ValueError(f"conv cache holds {cache.shape[0]} sequences, cu_seqlens {len(segs)}")
-            if mask is not None:
-                x = x.mul(mask.unsqueeze(-1))
             if x.dtype != torch.bfloat16:
                 raise ValueError(f"ShortConvolution kernel is built for bf16, got {x.dtype}")
             x = x.contiguous()
             D, W = x.shape[2], self.kernel_size[0]
+            if cache is not None and (cache.dtype != torch.bfloat16 or not cache.is_contiguous()
+                                      or tuple(cache.shape) != (len(segs), D, W)):
+                raise ValueError(f"conv cache must be a contiguous bf16 [N,D,W] = {(len(segs), D, W)} tensor (one row block per "
+                                 f"sequence of cu_seqlens); got {cache.dtype} {tuple(cache.shape)}")
             state_in = cache
             if cache is None and output_final_state:
                 cache = torch.zeros(len(segs), D, W, dtype=x.dtype, device=x.device)

@@ -25,7 +25,7 @@ for single in (False, True):
     ht = torch.zeros_like(h0)
     o = ops.gdn_chunk_fused(proj, cols, cw, so, so, A32, dt32, H, K, V, initial_state=h0, final_state_out=ht)
     torch.cuda.synchronize()
-    ws = ops.get_workspace(1, dev, "gdn")
+    ws = ops._gdn_workspace(1, ops._gdn_sync_area(dev))
     NT = (T + 63) // 64
     recs.append(ws[: B * H * NT * 62464].clone().view(B * H, NT, 62464).cpu())
 regions = dict(WN=(0, 16384), QH=(16384, 32768), KDT=(32768, 49152), AQK=(49152, 55296), EG=(55296, 55552), EGL=(55552, 55556),

@@ -1,0 +1,213 @@
+// PROTOTYPE (developer experiment, not part of libivl_hip.so): the 8-wave x 32-row x all-64-keys attention tile loop of
+// cdna_hip_programming.md Appendix B ("8-warp 32x32 ladder"), as a stand-alone kernel -- what VERDICT r4 #2 asks to be measured
+// BEFORE the product kernel is rebuilt around it.
+//   workgroup = 256 query rows of one head = 8 waves x 32 rows (two waves per SIMD, <= 256 VGPRs, no loader waves);
+//   a wave owns its 32 rows against ALL 64 keys of a tile: S^T = K Q^T on 2 x 8 v_mfma_f32_32x32x16_bf16 (two key halves, one
+//   shared row maximum), P^T packed in place, O^T += V^T P^T on 16 MFMAs -- 32 MFMAs per wave and tile between two barriers
+//   (the 128-row product kernel: 8 + 8 in two barrier segments, and a merge of the key halves at the end);
+//   K / V tiles: padded LDS images (K rows 272 B, V rows 320 B), a 3-stage ring filled by LDS-DMA issued by the COMPUTE waves
+//   (5 one-KB pieces per wave and tile, counted vmcnt, one barrier per tile).
+// MODE 0: the tile stays resident in LDS (compute-loop ceiling); 1: every tile is fetched again by DMA (the real data path, L2
+// hits); 2: MODE 1 + the QK^T product of tile t + 1 issued in front of the softmax of tile t (two score tiles live: T15).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __bf16 bf16_native2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) { const bf16_native2 v = {(__bf16)lo, (__bf16)hi}; return __builtin_bit_cast(unsigned int, v); }
+__device__ __forceinline__ mfma_bf16x8 mf(u32x4 v) { mfma_bf16x8 r; __builtin_memcpy(&r, &v, 16); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+constexpr int KS = 272, VS = 320, KT = 64, D = 128;
+constexpr int K_BYTES = KT * KS, V_BYTES = KT * VS, STAGE = K_BYTES + V_BYTES;      // 17,408 + 20,480 = 37,888 B
+constexpr int NST = 3;
+constexpr int DUMMY = NST * STAGE;                                                  // 1 KB landing area of the padding DMA pieces
+constexpr int LDS_BYTES = DUMMY + 1024;
+constexpr int NPIECE = 5;                                                           // DMA instructions per wave and tile (37 real + 3 dummy)
+
+template <int MODE>
+__global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                   bf16_t* __restrict__ o, int ntiles, float sc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
+  const int row0 = blockIdx.x * 256 + wave * 32;
+
+  // ---- DMA pieces of this wave: global piece index i = wave + 8 j (j < 5): K image pieces 0..16, V image pieces 17..36, >= 37 dummy
+  unsigned int src_off[NPIECE];         // per-lane byte offset into the [64][256 B] source tile (k or v)
+  unsigned int lds_off[NPIECE];         // wave-uniform byte offset inside a stage (or DUMMY - stage base: handled below)
+  bool is_v[NPIECE], dummy[NPIECE];
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {
+    const int i = wave + 8 * j;
+    dummy[j] = i >= 37;
+    is_v[j] = i >= 17;
+    const int c = is_v[j] ? i - 17 : i;
+    const int ppr = is_v[j] ? VS / 16 : KS / 16;
+    const int qd = 64 * c + lane, r = qd / ppr, col = qd % ppr;
+    const bool pad = col >= 16 || r >= KT || dummy[j];
+    src_off[j] = pad ? 0u : (unsigned int)(r * 256 + col * 16);
+    lds_off[j] = (unsigned int)((is_v[j] ? K_BYTES : 0) + 1024 * c);
+  }
+  const unsigned int lds_base = (unsigned int)(size_t)smem;
+  auto dma_tile = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const bf16_t* base = is_v[j] ? v : k;
+      const unsigned int dst = dummy[j] ? lds_base + DUMMY : lds_base + (unsigned int)st * STAGE + lds_off[j];
+      unsigned int keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src_off[j]), "s"(dst), "s"(base) : "memory");
+    }
+  };
+
+  // ---- Q^T fragments (B operand): lane = query row, d = 16 kd + 8 hi .. +7
+  u32x4 qf[8];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(q + (size_t)(row0 + l31) * D + 16 * kd + 8 * hi5);
+  f32x16 oacc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (MODE == 0) {
+    for (int i = tid; i < KT * 16; i += 512) {
+      const int r = i >> 4, c = i & 15;
+      *(u32x4*)(smem + r * KS + c * 16) = *(const u32x4*)(k + r * D + c * 8);
+      *(u32x4*)(smem + K_BYTES + r * VS + c * 16) = *(const u32x4*)(v + r * D + c * 8);
+    }
+  } else {
+    dma_tile(0);
+    dma_tile(1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // tile 0 landed (tile 1 may fly)
+  }
+  __syncthreads();
+
+  const int k_off = l31 * KS + 16 * hi5;
+  const int v_off = K_BYTES + (4 * hi5 + (l15 >> 2)) * VS + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
+
+  auto qk = [&](int st, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 fr[8];
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) fr[kd] = *(const u32x4*)(smem + st * STAGE + 32 * kh * KS + k_off + 32 * kd);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd]), mf(qf[kd]), s[kh], 0, 0, 0);
+    }
+  };
+  auto softmax = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) {
+    float rmax = vmax2(__builtin_fmaxf(s[0][0], s[0][1]), s[1][0]);
+    rmax = vmax3(rmax, s[0][2], s[0][3]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) rmax = vmax3(rmax, s[0][r], s[0][r + 1]);
+    rmax = vmax2(rmax, s[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) rmax = vmax3(rmax, s[1][r], s[1][r + 1]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    if (__any(m_new > m_run + 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+    const float mu = m_run;
+    float rsum = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r], sc, -mu));
+        s[kh][r] = p;
+        rsum += p;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        pf[kh][ks] = u32x4{pack2bf(s[kh][8 * ks + 0], s[kh][8 * ks + 1]), pack2bf(s[kh][8 * ks + 2], s[kh][8 * ks + 3]),
+                           pack2bf(s[kh][8 * ks + 4], s[kh][8 * ks + 5]), pack2bf(s[kh][8 * ks + 6], s[kh][8 * ks + 7])};
+    }
+    l_run += rsum;
+  };
+  auto pv = [&](int st, const u32x4 (&pf)[2][2]) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fv[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const unsigned char* vp = smem + st * STAGE + v_off + (32 * kh + 16 * ks) * VS + 64 * mt;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * VS));
+          u32x2 w0, w1;
+          __builtin_memcpy(&w0, &a0, 8);
+          __builtin_memcpy(&w1, &a1, 8);
+          fv[mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fv[mt]), mf(pf[kh][ks]), oacc[mt], 0, 0, 0);
+      }
+  };
+  auto tile_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  f32x16 sA[2], sB[2];
+  u32x4 pA[2][2];
+  if (MODE == 2) qk(0, sA);
+  int st = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int st2 = st == 0 ? 2 : st - 1;                 // (t + 2) % 3
+    const int st1 = st == 2 ? 0 : st + 1;                 // (t + 1) % 3
+    if (MODE != 0) dma_tile(st2);                         // tile t + 2 over tile t - 1 (its readers passed the barrier behind tile t - 1)
+    if (MODE == 2) {
+      // tile t + 1 landed before the barrier at the end of tile t - 1 ... its QK^T runs in front of this tile's softmax
+      if (t & 1) { qk(st1, sA); softmax(sB, pA); } else { qk(st1, sB); softmax(sA, pA); }
+      pv(st, pA);
+    } else {
+      qk(MODE == 0 ? 0 : st, sA);
+      softmax(sA, pA);
+      pv(MODE == 0 ? 0 : st, pA);
+    }
+    if (MODE != 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // own pieces of tile t + 1 landed (tile t + 2 may fly)
+    if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // MODE 2 reads tile t + 2's K one iteration early
+    tile_barrier();
+    st = st1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16_t* op = o + (size_t)(row0 + l31) * D + 32 * mt + 8 * qd + 4 * hi5;
+        *(u32x2*)op = u32x2{pack2bf(oacc[mt][4 * qd] * inv, oacc[mt][4 * qd + 1] * inv),
+                            pack2bf(oacc[mt][4 * qd + 2] * inv, oacc[mt][4 * qd + 3] * inv)};
+      }
+  }
+}
+extern "C" int attn8_proto_launch(const void* q, const void* k, const void* v, void* o, int rows, int ntiles, float sc, int mode, void* stream) {
+  dim3 grid(rows / 256), block(512);
+#define GO(M) { (void)hipFuncSetAttribute((const void*)attn8_proto<M>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+    hipLaunchKernelGGL((attn8_proto<M>), grid, block, LDS_BYTES, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc); }
+  if (mode == 0) GO(0) else if (mode == 1) GO(1) else GO(2)
+  return (int)hipGetLastError();
+}
