@@ -1041,6 +1041,451 @@ __global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Prefill kernel, round 5: the tile loop rebuilt on the 8-wave structure of cdna_hip_programming.md Appendix B,
+// measured first as a stand-alone prototype (tools/proto/attn8_proto.hip, MODE 7: 894-914 TFLOP/s against 742-760 for the kernel
+// above on the same box).  Same decomposition as above -- 128 query rows of one head, 8 compute waves = 4 row groups x 2 key halves
+// on v_mfma_f32_32x32x16_bf16, lane-local rows, P^T packed in place, key halves merged once at the end -- but:
+//   * NO loader waves: 512 threads, two waves per SIMD with up to 256 VGPRs each.  The compute waves issue the LDS-DMA themselves:
+//     a tile is 2 x 16 one-KB pieces = 4 per wave, issued in the VALU-only stretch between the row maximum and the exponentials
+//     (an LDS-DMA piece costs the issuing wave 25-60 cycles there, 100-185 beside LDS reads: MI355X_MICROARCH.md).
+//   * ONE barrier per tile (16 MFMAs per wave between barriers instead of 8): a 3-stage ring; tile t + 2 is requested during
+//     tile t into the stage tile t - 1 left at the previous barrier, and awaited (counted vmcnt) before the barrier that ends tile t + 1.
+//   * the key-half-1 waves (the SIMD partners of the key-half-0 waves) run their phases ROTATED by one: softmax(t), PV(t), then
+//     QK^T(t + 1) -- the partner's QK^T MFMAs face this wave's softmax VALU and the partner's softmax faces this wave's PV MFMAs
+//     (the round-2 kernel skewed the halves by a barrier segment; with one barrier per tile the skew is in the program order).
+//   * unpadded 64 x 256 B images, XOR-swizzled on the SOURCE side of the DMA (the LDS side of a DMA piece is lane-linear): K
+//     16-byte piece p of row r sits at p ^ (r & 15) (conflict-free for the 32-row ds_read_b128 pattern), V 64-byte granule g of
+//     row r at g ^ (r & 3) (conflict-free for ds_read_b64_tr_b16); a fragment address is base ^ (kd << 5) | base ^ (mt << 6).
+//   * wrap / seam / tail tiles and un-rotated keys of a short fused-rope call go through registers in the compute waves (the
+//     same lane -> (row, piece) map as a DMA piece, so the swizzle is shared): at most three such tiles per 68-tile row.
+// Band, split-KV partial rows, merge epilogue, block order: as above.
+constexpr int P8_THREADS = 768;                                  // 8 compute wavefronts + 4 loader wavefronts (3 per SIMD: <= 168 VGPRs)
+constexpr int P8_IMG = SWA_KT * 256;                              // 16 KB per image
+constexpr int P8_STAGE = 2 * P8_IMG;                              // K | V
+constexpr int P8_STAGES = 3;
+constexpr int P8_LDS_BYTES = P8_STAGES * P8_STAGE;                // 96 KB
+static_assert(PF_ML_OFF + 128 * 8 <= P8_LDS_BYTES, "merge image must fit the K/V stages");
+
+__global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[P8_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
+  const bool loader = wave >= 8;
+  const int rg = wave & 3, kh = (wave >> 2) & 1;
+  int bx, rest;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = nwg >> 3, rn = nwg & 7;
+    if (rn == 0 && qn % p.n_qtiles == 0) {
+      const int hx = qn / p.n_qtiles;
+      const int r = slot / hx, half = (p.n_qtiles + 1) >> 1;
+      bx = qn > 32 ? p.n_qtiles - 1 - r : (r < half ? p.n_qtiles - 1 - r : r - half);
+      rest = xcd * hx + slot % hx;
+    } else {
+      const int lid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+      bx = lid % p.n_qtiles;
+      rest = lid / p.n_qtiles;
+    }
+  }
+  const int G = p.Hq / p.Hkv;
+  const int hq = rest % p.Hq, bz = rest / p.Hq;
+  const int b = bz / p.nsplit, split = bz % p.nsplit;
+  const int hk = hq / G;
+  IVL_T(tr_start);
+
+  // the position comes through a vector load (the pointer is not provably read-only): everything derived from it -- ring geometry,
+  // tile kinds, DMA addresses, the dead-tile tests -- must live in SGPRs, or every test on it becomes a lane-mask operation and
+  // every address a 64-bit VALU chain (measured: 480-1,060 cycles per tile for the four DMA pieces of a wave)
+  const long long pos_v = p.pos_dev ? *p.pos_dev : p.pos;
+  const long long pos = (long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)pos_v >> 32)) << 32) |
+                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)pos_v));
+  const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
+  const int n_prev = n_ring + (p.T_new - p.T);
+  const int S = n_prev + p.T;
+  const int s0 = __builtin_amdgcn_readfirstlane(p.C > 0 ? mod_pos(pos - n_ring, p.C) : 0);
+
+  const int tile_row0 = bx * PF_QT;
+  const int last_row = min(tile_row0 + PF_QT, p.T) - 1;
+  const int lo_min = p.W > 0 ? max(0, n_prev + tile_row0 - p.W + 1) : 0;
+  const int kt0 = lo_min / SWA_KT, kt1 = (n_prev + last_row) / SWA_KT + 1;
+  const int per = __builtin_amdgcn_readfirstlane((kt1 - kt0 + p.nsplit - 1) / p.nsplit);
+  const int kt_begin = kt0 + split * per;
+  const int kt_end = min(kt1, kt_begin + per);
+  const int n = max(kt_end - kt_begin, 0);            // workgroup-uniform
+
+  // ---- staging (loader waves 8-11): loader L takes the 4-row chunks c = L + 4 j (j < 4) of both images: 8 DMA pieces per tile ----
+  const int r_in = lane >> 4, pp = lane & 15;
+  const unsigned int k_piece = (unsigned int)((pp ^ (4 * (wave & 3) + r_in)) << 4);                 // source byte offset inside the row
+  const unsigned int v_piece = (unsigned int)(((((pp >> 2) ^ r_in) << 2) | (pp & 3)) << 4);
+  const int chunk0 = wave & 3;                                                                      // + 4 j
+  const unsigned int lds_base = (unsigned int)(size_t)smem;
+  const long long ring_off = p.C > 0 ? (((long long)b * p.Hkv + hk) * p.C) * SWA_D : 0;
+  const bf16_t* const k_ring = p.C > 0 ? p.k_cache + ring_off : p.k_new;
+  const bf16_t* const v_ring = p.C > 0 ? p.v_cache + ring_off : p.v_new;
+  const bf16_t* const k_newb = p.k_new + (long long)b * p.kn_sb + (long long)hk * p.kn_sh;
+  const bf16_t* const v_newb = p.v_new + (long long)b * p.vn_sb + (long long)hk * p.vn_sh;
+  const unsigned int kn_st32 = (unsigned int)p.kn_st, vn_st32 = (unsigned int)p.vn_st;
+  const bool rope_keys = p.rcos != nullptr;             // the call's keys arrive un-rotated (short single-split calls only)
+  auto dma_piece = [&](const unsigned char* base_u, unsigned int voff, unsigned int dst) __attribute__((always_inline)) {
+    const unsigned long long bu = (unsigned long long)base_u;
+    const unsigned char* const base = (const unsigned char*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(bu >> 32)) << 32) |
+                                                             (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)bu));
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+  };
+  // tile kinds, monotone in kt: [0, kt_ring_end) lie wholly in the ring (all but the one that holds the wrap point are 64 consecutive
+  // slots), [kt_new_begin, kt_new_end) wholly in the call's keys; the rest (wrap, ring / new seam, tail) take the register path
+  const int kt_ring_end = n_ring / SWA_KT, kt_new_begin = (n_ring + SWA_KT - 1) / SWA_KT, kt_new_end = S / SWA_KT;
+  const int kt_wrap = (p.C > 0 && s0 + n_ring > p.C) ? (p.C - s0) / SWA_KT : -1;       // the tile with slots on both sides of the wrap
+  const bool wrap_aligned = p.C > 0 && (p.C - s0) % SWA_KT == 0;                         // ... unless the wrap falls on a tile boundary
+  // tile kt of the call into stage `st`; returns the number of DMA instructions this wave issued (0, 4 or 8)
+  auto stage_tile = [&](int kt, int st) __attribute__((always_inline)) -> int {
+    const int j0 = kt * SWA_KT, slot0 = s0 + j0;
+    const bool ring_fast = kt < kt_ring_end && (kt != kt_wrap || wrap_aligned);
+    const bool new_fast = kt >= kt_new_begin && kt < kt_new_end;
+    int issued = 0;
+#pragma unroll
+    for (int isv = 0; isv < 2; ++isv) {
+      const unsigned int img = lds_base + (unsigned int)st * P8_STAGE + (isv ? (unsigned int)P8_IMG : 0u);
+      const unsigned int piece = isv ? v_piece : k_piece;
+      const unsigned int st32 = isv ? vn_st32 : kn_st32;
+      const bf16_t* const rb = isv ? v_ring : k_ring;
+      const bf16_t* const nb = isv ? v_newb : k_newb;
+      if (ring_fast) {
+        const unsigned char* src = (const unsigned char*)(rb + (long long)(slot0 >= p.C ? slot0 - p.C : slot0) * SWA_D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(src + (chunk0 + 4 * j) * 1024, (unsigned int)(r_in * 256) + piece, img + 1024u * (chunk0 + 4 * j));
+        issued += 4;
+      } else if (new_fast && !(isv == 0 && rope_keys)) {
+        const unsigned char* src = (const unsigned char*)(nb + (long long)(j0 - n_ring) * st32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dma_piece(src + (long long)(chunk0 + 4 * j) * 4 * st32 * 2, (unsigned int)r_in * st32 * 2 + piece, img + 1024u * (chunk0 + 4 * j));
+        issued += 4;
+      } else {
+        // register path (ring wrap, ring / new seam, tail, un-rotated keys): clamped loads from both sources, rows past the end
+        // are zero, the call's keys are rotated; written with the lane -> (row, piece) map of a DMA piece
+        u32x4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int jk = j0 + 4 * (chunk0 + 4 * j) + r_in;
+          const int jc = min(jk, S - 1);
+          int slot = s0 + min(jc, max(n_ring - 1, 0));
+          slot = slot >= p.C ? slot - p.C : slot;
+          const u32x4 a0 = *(const u32x4*)((const unsigned char*)(rb + (unsigned int)slot * SWA_D) + piece);
+          const u32x4 c0 = *(const u32x4*)((const unsigned char*)(nb + (unsigned int)max(jc - n_ring, 0) * st32) + piece);
+          u32x4 val = jc < n_ring ? a0 : c0;
+          if (isv == 0 && rope_keys && jc >= n_ring) {
+            const int jn = jc - n_ring;
+            const u32x4 part = *(const u32x4*)((const unsigned char*)(nb + (unsigned int)jn * st32) + (piece ^ 128u));
+            const bool is_lo = piece < 128u;
+            u32x4 lo = is_lo ? val : part, hi = is_lo ? part : val;
+            rope_pair(lo, hi, p.rcos, p.rsin, (long long)p.B * p.T * SWA_D, ((long long)b * p.T + jn) * SWA_D, (int)((piece & 127u) >> 1), p.rs0, p.rs1);
+            val = is_lo ? lo : hi;
+          }
+          r[j] = jk < S ? val : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4*)(smem + st * P8_STAGE + (isv ? P8_IMG : 0) + 1024 * (chunk0 + 4 * j) + 16 * lane) = r[j];
+      }
+    }
+    return issued;
+  };
+
+  if (loader) {
+    // ---- loader wavefronts: per tile  [request tile t + 2 over tile t - 1] | vmcnt: tile t + 1 has landed | barrier ---------------
+    auto land = [&](int fly) __attribute__((always_inline)) {            // `fly` younger DMA instructions may stay in flight
+      __builtin_amdgcn_sched_barrier(0);
+      if (fly == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (fly == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (n > 0) stage_tile(kt_begin, 0);
+    if (n > 1) stage_tile(kt_begin + 1, 1);
+    land(0);                                                              // tiles 0 and 1 are in LDS: the compute waves start
+    int st2 = 2;
+#pragma nounroll
+    for (int t = 0; t < n; ++t) {
+      const int fly = t + 2 < n ? stage_tile(kt_begin + t + 2, st2) : 0;
+      land(fly);
+      st2 = st2 == 2 ? 0 : st2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                      // the three barriers of the merge epilogue
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
+
+  // ---- compute-side set-up ----------------------------------------------------------------------------------------------------
+  const int row = tile_row0 + 32 * rg + l31;
+  const bool row_ok = row < p.T;
+  const int band_hi = n_prev + row;
+  const int band_lo = p.W > 0 ? max(0, n_prev + row - p.W + 1) : 0;
+  const int wr0 = tile_row0 + 32 * rg, wr1 = max(min(wr0 + 31, p.T - 1), wr0);
+  const int w_hi_min = n_prev + wr0, w_hi_max = n_prev + wr1;
+  const int w_lo_min = p.W > 0 ? max(0, n_prev + wr0 - p.W + 1) : 0;
+  const int w_lo_max = p.W > 0 ? max(0, n_prev + wr1 - p.W + 1) : 0;
+  u32x4 qf[8];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(row, p.T - 1) * p.q_st + (long long)hq * p.q_sh;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qp + 16 * kd + 8 * hi5);
+  }
+  if (p.rcos != nullptr) {
+    const long long row_off = ((long long)b * p.T + min(row, p.T - 1)) * SWA_D;
+    const long long plane = (long long)p.B * p.T * SWA_D;
+    u32x4 c1[4], n1[4], c2[4], n2[4];
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) {
+      const int c0 = 16 * kd + 8 * hi5;
+      const int sec = c0 < p.rs0 ? 0 : (c0 < p.rs0 + p.rs1 ? 1 : 2);
+      const long long off = sec * plane + row_off + c0;
+      c1[kd] = *(const u32x4*)(p.rcos + off); n1[kd] = *(const u32x4*)(p.rsin + off);
+      c2[kd] = *(const u32x4*)(p.rcos + off + 64); n2[kd] = *(const u32x4*)(p.rsin + off + 64);
+    }
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) rope_apply(qf[kd], qf[kd + 4], c1[kd], n1[kd], c2[kd], n2[kd]);
+  }
+  if (!row_ok) {
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) qf[kd] = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  const float sc = p.scaling * LOG2E;
+  const unsigned int k_base = (unsigned int)((32 * kh + l31) * 256 + ((l15 >> 1) << 5) + ((hi5 ^ (l15 & 1)) << 4));
+  const unsigned int v_base = (unsigned int)(P8_IMG + (32 * kh + 4 * hi5 + (l15 >> 2)) * 256 + ((l15 >> 2) << 6) + 32 * ((lane >> 4) & 1) + 8 * (l15 & 3));
+  unsigned int ak[8], av[4];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) ak[kd] = k_base ^ (unsigned int)(kd << 5);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) av[mt] = v_base ^ (unsigned int)(mt << 6);
+
+  auto is_dead = [&](int kt) __attribute__((always_inline)) {                // no row of the wave sees any of its 32 keys of tile kt
+    const int kbeg = kt * SWA_KT + 32 * kh;
+    return kbeg > w_hi_max || kbeg + 31 < w_lo_min;
+  };
+  auto qk = [&](int st, f32x16& s) __attribute__((always_inline)) {
+    const unsigned int so = (unsigned int)st * P8_STAGE;
+    u32x4 fr[8];
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) fr[kd] = *(const u32x4*)(smem + (ak[kd] + so));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[kd]), as_mfma(qf[kd]), s, 0, 0, 0);
+  };
+  auto row_max = [&](int kt, f32x16& s) __attribute__((always_inline)) {     // band mask, lazy exponent reference, rescale (see swa_prefill_kernel)
+    const int kbeg = kt * SWA_KT + 32 * kh;
+    const bool interior = kbeg >= w_lo_max && kbeg + 31 <= w_hi_min;
+    if (!interior) {
+      const int jb = kbeg + 4 * hi5;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jb + (r & 3) + 8 * (r >> 2);
+        const bool vis = row_ok && j >= band_lo && j <= band_hi;
+        s[r] = vis ? s[r] : -INFINITY;
+      }
+    }
+    float rmax = vmax2(__builtin_fmaxf(s[0], s[1]), s[2]);       // first reader of the MFMA results: compiler-visible (hazard wait states)
+    rmax = vmax3(rmax, s[3], s[4]);
+    rmax = vmax3(rmax, s[5], s[6]);
+    rmax = vmax3(rmax, s[7], s[8]);
+    rmax = vmax3(rmax, s[9], s[10]);
+    rmax = vmax3(rmax, s[11], s[12]);
+    rmax = vmax3(rmax, s[13], s[14]);
+    rmax = vmax2(rmax, s[15]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    if (__any(m_new > m_run + 8.0f)) {
+      const float m_u = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+  };
+  auto exps = [&](f32x16& s, u32x4 (&pf)[2]) __attribute__((always_inline)) {
+    const float m_use = m_run == -INFINITY ? 0.f : m_run;
+    float rsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc, -m_use));
+      s[r] = pv;
+      rsum += pv;
+    }
+    l_run += rsum;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      pf[ks] = u32x4{pack2bf(s[8 * ks + 0], s[8 * ks + 1]), pack2bf(s[8 * ks + 2], s[8 * ks + 3]),
+                     pack2bf(s[8 * ks + 4], s[8 * ks + 5]), pack2bf(s[8 * ks + 6], s[8 * ks + 7])};
+  };
+  auto pv = [&](int st, const u32x4 (&pf)[2]) __attribute__((always_inline)) {
+    const unsigned int so = (unsigned int)st * P8_STAGE;
+    u32x4 fv[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const unsigned char* vp = smem + (av[mt] + so) + 16 * ks * 256;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * 256));
+        u32x2 w0, w1;
+        __builtin_memcpy(&w0, &a0, 8);
+        __builtin_memcpy(&w1, &a1, 8);
+        fv[ks][mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fv[ks][mt]), as_mfma(pf[ks]), oacc[mt], 0, 0, 0);
+  };
+  // the barrier that ends a tile: nobody reads the current tile any more; the loaders arrive with the next tile in LDS
+  auto tile_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  tile_barrier();                              // tiles 0 and 1 are in LDS
+
+  IVL_T(tr_loop);
+  IVL_TVAR(tr_c1); IVL_TVAR(tr_st); IVL_TVAR(tr_c2); IVL_TVAR(tr_w);
+  f32x16 sA;
+  u32x4 pA[2];
+  int st = 0;                                  // stage of tile t = t % 3
+  if (kh == 0) {
+    // key half 0:  QK^T(t) | row max | exponentials | PV(t) | barrier
+#pragma nounroll
+    for (int t = 0; t < n; ++t) {
+      const int kt = kt_begin + t;
+      const bool dead = is_dead(kt);
+      IVL_T(t0);
+      if (!dead) {
+        qk(st, sA);
+        row_max(kt, sA);
+      }
+      IVL_T(t1);
+      IVL_T(t2);
+      if (!dead) {
+        exps(sA, pA);
+        pv(st, pA);
+      }
+      IVL_T(t3);
+      tile_barrier();
+      IVL_T(t4);
+      IVL_TACC(tr_c1, t1, t0); IVL_TACC(tr_st, t2, t1); IVL_TACC(tr_c2, t3, t2); IVL_TACC(tr_w, t4, t3);
+      st = st == 2 ? 0 : st + 1;
+    }
+  } else {
+    // key half 1, rotated:  row max(t) | exponentials | PV(t) | QK^T(t + 1) | barrier
+    // (tile t + 1 is complete since the barrier that ended tile t - 1)
+    if (n > 0 && !is_dead(kt_begin)) qk(0, sA);
+#pragma nounroll
+    for (int t = 0; t < n; ++t) {
+      const int kt = kt_begin + t;
+      const bool dead = is_dead(kt);
+      IVL_T(t0);
+      if (!dead) row_max(kt, sA);
+      IVL_T(t1);
+      const int st1 = st == 2 ? 0 : st + 1;
+      IVL_T(t2);
+      if (!dead) {
+        exps(sA, pA);
+        pv(st, pA);
+      }
+      if (t + 1 < n && !is_dead(kt + 1)) qk(st1, sA);       // (the scores of tile t are packed in pA by now)
+      IVL_T(t3);
+      tile_barrier();
+      IVL_T(t4);
+      IVL_TACC(tr_c1, t1, t0); IVL_TACC(tr_st, t2, t1); IVL_TACC(tr_c2, t3, t2); IVL_TACC(tr_w, t4, t3);
+      st = st1;
+    }
+  }
+  IVL_T(tr_end);
+
+  // ---- merge the two key halves of every row group through LDS, then whole-row stores (as swa_prefill_kernel) ------------------
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  __syncthreads();
+  unsigned char* oimg = smem + rg * 32 * PF_OSTRIDE + l31 * PF_OSTRIDE + 16 * hi5;      // + 128 mt + 32 q : d = 32 mt + 8 q + 4 hi
+  float* ml = (float*)(smem + PF_ML_OFF) + (rg * 32 + l31) * 2;
+  if (kh == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(oimg + 128 * mt + 32 * q) = f32x4{oacc[mt][4 * q], oacc[mt][4 * q + 1], oacc[mt][4 * q + 2], oacc[mt][4 * q + 3]};
+    if (hi5 == 0) {
+      ml[0] = m_run;
+      ml[1] = l_run;
+    }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const float m1 = ml[0], l1 = ml[1];
+    const float m = vmax2(m_run, m1);
+    const float mu = m == -INFINITY ? 0.f : m;
+    const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
+    const float l = l_run * a0 + l1 * a1;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;      // normalised rows also for the split-KV partials (stored in bf16)
+    const float w0 = a0 * inv, w1 = a1 * inv;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o1 = *(const f32x4*)(oimg + 128 * mt + 32 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = oacc[mt][4 * q + e] * w0 + o1[e] * w1;
+        *(f32x4*)(oimg + 128 * mt + 32 * q) = o;
+      }
+    if (hi5 == 0) {
+      ml[0] = m;
+      ml[1] = l;
+    }
+  }
+  __syncthreads();
+  {
+    bf16_t* const dst = p.nsplit == 1 ? p.o : (bf16_t*)p.part_o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;       // row, 8-channel piece
+      const int t = tile_row0 + r;
+      if (t < p.T) {
+        const unsigned char* src = smem + r * PF_OSTRIDE + c * 32;
+        const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
+        const long long orow = p.nsplit == 1 ? ((long long)b * p.T + t) * p.Hq + hq
+                                             : (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
+        *(u32x4*)(dst + orow * SWA_D + 8 * c) =
+            u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+      }
+    }
+    if (p.nsplit > 1 && tid < PF_QT && tile_row0 + tid < p.T) {
+      const long long prow = (((long long)b * p.nsplit + split) * p.T + tile_row0 + tid) * p.Hq + hq;
+      *(float2*)(p.part_ml + prow * 2) = *(const float2*)(smem + PF_ML_OFF + tid * 8);
+    }
+  }
+  IVL_T(tr_fin);
+  IVL_TOUT(32, tr_loop - tr_start); IVL_TOUT(38, tr_fin - tr_end); IVL_TOUT(39, tr_fin - tr_start); IVL_TOUT(40, kt_end - kt_begin);
+  IVL_TOUT(47, tr_end - tr_loop); IVL_TOUT(42, 2);
+  IVL_TOUT(33, tr_c1); IVL_TOUT(34, tr_st); IVL_TOUT(35, tr_c2); IVL_TOUT(36, tr_w);
+  IVL_TOUT_AT(256, 50, tr_c1); IVL_TOUT_AT(256, 51, tr_st); IVL_TOUT_AT(256, 52, tr_c2); IVL_TOUT_AT(256, 53, tr_w);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // fp8 (e4m3) variant of the packed DECODE step (BASELINE.json configs[4]; the reference has no such path): q, the K / V
 // tile and the probabilities are rounded to OCP e4m3 and both products run on v_mfma_f32_16x16x32_fp8_fp8; scores, the
 // online softmax, the row sums and the output accumulators stay fp32.  Same band, same split-KV partials and combine
@@ -1526,7 +1971,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   }
   p.n_qtiles = prefill ? (rows + PF_QT - 1) / PF_QT : (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
-  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(PF_THREADS), 0, st, p);
+  if (prefill) hipLaunchKernelGGL(swa_prefill8_kernel, grid, dim3(P8_THREADS), 0, st, p);
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
     hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
   else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);

@@ -8,9 +8,11 @@
 //   K / V tiles: padded LDS images (K rows 272 B, V rows 320 B), a 3-stage ring filled by LDS-DMA issued by the COMPUTE waves
 //   (5 one-KB pieces per wave and tile, counted vmcnt, one barrier per tile).
 // MODE 0: the tile stays resident in LDS (compute-loop ceiling); 1: every tile is fetched again by DMA (the real data path, L2
-// hits); 2: MODE 1 + the QK^T product of tile t + 1 issued in front of the softmax of tile t (two score tiles live: T15).
+// hits), pieces issued right behind the barrier; 3: pieces issued between the row maximum and the exponentials; 4: MODE 3 + the
+// second half of the waves runs its phases rotated by one (softmax, PV, QK^T of the next tile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -32,7 +34,7 @@ constexpr int LDS_BYTES = DUMMY + 1024;
 constexpr int NPIECE = 5;                                                           // DMA instructions per wave and tile (37 real + 3 dummy)
 
 template <int MODE>
-__global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn8_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                    bf16_t* __restrict__ o, int ntiles, float sc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,6 +73,11 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
   u32x4 qf[8];
 #pragma unroll
   for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(q + (size_t)(row0 + l31) * D + 16 * kd + 8 * hi5);
+  // the compiler's vmcnt bookkeeping must see the Q loads complete BEFORE the loop: it does not model the inline-asm DMA, and a
+  // pending load at the loop header makes it place vmcnt(7..0) waits in front of the first MFMAs of every iteration -- which in
+  // the steady state wait for the DMA pieces issued a few instructions earlier
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) asm volatile("" : "+v"(qf[kd]));
   f32x16 oacc[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -95,18 +102,21 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
   const int v_off = K_BYTES + (4 * hi5 + (l15 >> 2)) * VS + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
 
   auto qk = [&](int st, f32x16 (&s)[2]) {
+    u32x4 fr[2][8];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      u32x4 fr[8];
+    for (int kd = 0; kd < 8; ++kd)
 #pragma unroll
-      for (int kd = 0; kd < 8; ++kd) fr[kd] = *(const u32x4*)(smem + st * STAGE + 32 * kh * KS + k_off + 32 * kd);
+      for (int kh = 0; kh < 2; ++kh) fr[kh][kd] = *(const u32x4*)(smem + st * STAGE + 32 * kh * KS + k_off + 32 * kd);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
 #pragma unroll
-      for (int kd = 0; kd < 8; ++kd) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd]), mf(qf[kd]), s[kh], 0, 0, 0);
-    }
+    for (int kd = 0; kd < 8; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kh][kd]), mf(qf[kd]), s[kh], 0, 0, 0);
   };
-  auto softmax = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) {
+  auto smax = [&](f32x16 (&s)[2]) {
     float rmax = vmax2(__builtin_fmaxf(s[0][0], s[0][1]), s[1][0]);
     rmax = vmax3(rmax, s[0][2], s[0][3]);
 #pragma unroll
@@ -124,6 +134,8 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
       l_run *= alpha;
       m_run = m_new;
     }
+  };
+  auto sexp = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) {
     const float mu = m_run;
     float rsum = 0.f;
 #pragma unroll
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
     }
     l_run += rsum;
   };
+  auto softmax = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) { smax(s); sexp(s, pf); };
   auto pv = [&](int st, const u32x4 (&pf)[2][2]) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -169,25 +182,60 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
 
   f32x16 sA[2], sB[2];
   u32x4 pA[2][2];
-  if (MODE == 2) qk(0, sA);
   int st = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const int st2 = st == 0 ? 2 : st - 1;                 // (t + 2) % 3
-    const int st1 = st == 2 ? 0 : st + 1;                 // (t + 1) % 3
-    if (MODE != 0) dma_tile(st2);                         // tile t + 2 over tile t - 1 (its readers passed the barrier behind tile t - 1)
-    if (MODE == 2) {
-      // tile t + 1 landed before the barrier at the end of tile t - 1 ... its QK^T runs in front of this tile's softmax
-      if (t & 1) { qk(st1, sA); softmax(sB, pA); } else { qk(st1, sB); softmax(sA, pA); }
-      pv(st, pA);
-    } else {
+  if (MODE <= 1) {
+    for (int t = 0; t < ntiles; ++t) {
+      const int st2 = st == 0 ? 2 : st - 1;                 // (t + 2) % 3
+      const int st1 = st == 2 ? 0 : st + 1;                 // (t + 1) % 3
+      if (MODE != 0) dma_tile(st2);                         // tile t + 2 over tile t - 1 (its readers passed the barrier behind tile t - 1)
       qk(MODE == 0 ? 0 : st, sA);
       softmax(sA, pA);
       pv(MODE == 0 ? 0 : st, pA);
+      if (MODE != 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // own pieces of tile t + 1 landed (tile t + 2 may fly)
+      tile_barrier();
+      st = st1;
     }
-    if (MODE != 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // own pieces of tile t + 1 landed (tile t + 2 may fly)
-    if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // MODE 2 reads tile t + 2's K one iteration early
-    tile_barrier();
-    st = st1;
+  } else if (MODE == 3 || wave < 4) {
+    // DMA pieces issued between the row maximum and the exponentials (VALU-only stretch)
+    for (int t = 0; t < ntiles; ++t) {
+      const int st2 = st == 0 ? 2 : st - 1, st1 = st == 2 ? 0 : st + 1;
+      qk(st, sA);
+      smax(sA);
+      dma_tile(st2);
+      sexp(sA, pA);
+      pv(st, pA);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      tile_barrier();
+      st = st1;
+    }
+  } else {
+    // MODE 4, second half of the workgroup (the SIMD partners of waves 0-3): the same work ROTATED by one phase -- softmax(t),
+    // PV(t), QK(t + 1) -- so that the partner's QK^T faces this wave's softmax and the partner's softmax this wave's PV
+    qk(0, sA);
+    for (int t = 0; t < ntiles; t += 2) {
+      {
+        const int st2 = st == 0 ? 2 : st - 1, st1 = st == 2 ? 0 : st + 1;
+        smax(sA);
+        dma_tile(st2);
+        sexp(sA, pA);
+        pv(st, pA);
+        qk(st1, sB);                                        // tile t + 1: complete since the barrier behind tile t - 1
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        tile_barrier();
+        st = st1;
+      }
+      {
+        const int st2 = st == 0 ? 2 : st - 1, st1 = st == 2 ? 0 : st + 1;
+        smax(sB);
+        dma_tile(st2);
+        sexp(sB, pA);
+        pv(st, pA);
+        if (t + 2 < ntiles) qk(st1, sA);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        tile_barrier();
+        st = st1;
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
@@ -204,10 +252,377 @@ __global__ __launch_bounds__(512) void attn8_proto(const bf16_t* __restrict__ q,
       }
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 4-wave form: workgroup = 128 query rows = 4 waves x 32 rows x all 64 keys, ONE wave per SIMD and workgroup, TWO workgroups per
+// CU (two 32 KB stages each): the two waves of a SIMD belong to different workgroups and drift apart freely -- the stagger of
+// MODE 4 without a second code path, at the granularity (128 rows) that balances a causal call.  K / V images unpadded
+// (64 x 256 B), XOR-swizzled on the SOURCE side of the DMA: K 16-byte piece p of row r at p ^ (r & 15), V 64-byte granule g of
+// row r at g ^ (r & 3): 32 one-KB pieces per tile = 8 per wave, none wasted.
+constexpr int STAGE4 = 2 * KT * 256;                     // 32 KB
+template <int NSTG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn4_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                                             const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int ntiles, float sc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
+  const int row0 = blockIdx.x * 128 + wave * 32;
+  const unsigned int lds_base = (unsigned int)(size_t)smem;
+  // DMA: chunks c = wave + 4 j (rows 4c .. 4c + 3) of both images
+  const int r_in = lane >> 4, pp = lane & 15;
+  const unsigned int k_src = (unsigned int)(r_in * 256 + ((pp ^ (4 * wave + r_in)) << 4));
+  const unsigned int v_src = (unsigned int)(r_in * 256 + (((((pp >> 2) ^ r_in) << 2) | (pp & 3)) << 4));
+  auto dma_tile = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave + 4 * j;
+#pragma unroll
+      for (int isv = 0; isv < 2; ++isv) {
+        const unsigned char* base = (const unsigned char*)(isv ? v : k) + (size_t)c * 1024;      // 4 rows x 256 B per chunk
+        const unsigned int dst = lds_base + (unsigned int)st * STAGE4 + (isv ? 16384u : 0u) + 1024u * c;
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(isv ? v_src : k_src), "s"(dst), "s"(base) : "memory");
+      }
+    }
+  };
+  u32x4 qf[8];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(q + (size_t)(row0 + l31) * D + 16 * kd + 8 * hi5);
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) asm volatile("" : "+v"(qf[kd]));
+  f32x16 oacc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // fragment addresses: K row 32 kh + l31, piece (2 kd + hi5) ^ l15  ==  base ^ (kd << 5);  V granule (mt ^ rr)  ==  base ^ (mt << 6)
+  const unsigned int k_base = (unsigned int)(l31 * 256 + ((l15 >> 1) << 5) + ((hi5 ^ (l15 & 1)) << 4));
+  const unsigned int v_base = (unsigned int)(16384 + (4 * hi5 + (l15 >> 2)) * 256 + ((l15 >> 2) << 6) + 32 * ((lane >> 4) & 1) + 8 * (l15 & 3));
+  unsigned int ak[8], av[4];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) ak[kd] = k_base ^ (unsigned int)(kd << 5);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) av[mt] = v_base ^ (unsigned int)(mt << 6);
+
+  auto qk = [&](int st, f32x16 (&s)[2]) {
+    u32x4 fr[2][8];
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) fr[kh][kd] = *(const u32x4*)(smem + ak[kd] + st * STAGE4 + 32 * kh * 256);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kh][kd]), mf(qf[kd]), s[kh], 0, 0, 0);
+  };
+  auto smax = [&](f32x16 (&s)[2]) {
+    float rmax = vmax2(__builtin_fmaxf(s[0][0], s[0][1]), s[1][0]);
+    rmax = vmax3(rmax, s[0][2], s[0][3]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) rmax = vmax3(rmax, s[0][r], s[0][r + 1]);
+    rmax = vmax2(rmax, s[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) rmax = vmax3(rmax, s[1][r], s[1][r + 1]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    if (__any(m_new > m_run + 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+  };
+  auto sexp = [&](f32x16 (&s)[2], u32x4 (&pf)[2][2]) {
+    const float mu = m_run;
+    float rsum = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r], sc, -mu));
+        s[kh][r] = p;
+        rsum += p;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        pf[kh][ks] = u32x4{pack2bf(s[kh][8 * ks + 0], s[kh][8 * ks + 1]), pack2bf(s[kh][8 * ks + 2], s[kh][8 * ks + 3]),
+                           pack2bf(s[kh][8 * ks + 4], s[kh][8 * ks + 5]), pack2bf(s[kh][8 * ks + 6], s[kh][8 * ks + 7])};
+    }
+    l_run += rsum;
+  };
+  auto pv = [&](int st, const u32x4 (&pf)[2][2]) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fv[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const unsigned char* vp = smem + av[mt] + st * STAGE4 + (32 * kh + 16 * ks) * 256;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * 256));
+          u32x2 w0, w1;
+          __builtin_memcpy(&w0, &a0, 8);
+          __builtin_memcpy(&w1, &a1, 8);
+          fv[mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fv[mt]), mf(pf[kh][ks]), oacc[mt], 0, 0, 0);
+      }
+  };
+  auto tile_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x16 sA[2];
+  u32x4 pA[2][2];
+  auto step = [&](auto st_tag, bool more) {
+    constexpr int ST = decltype(st_tag)::value;
+    qk(ST, sA);
+    smax(sA);
+    if (more) dma_tile(ST ^ 1);                            // tile t + 1 over tile t - 1 (its readers passed the barrier behind tile t - 1)
+    sexp(sA, pA);
+    pv(ST, pA);
+    tile_barrier();                                        // own pieces of tile t + 1 landed; everybody is done with tile t
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(std::integral_constant<int, 0>{}, t + 1 < ntiles);
+    step(std::integral_constant<int, 1>{}, t + 2 < ntiles);
+  }
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16_t* op = o + (size_t)(row0 + l31) * D + 32 * mt + 8 * qd + 4 * hi5;
+        *(u32x2*)op = u32x2{pack2bf(oacc[mt][4 * qd] * inv, oacc[mt][4 * qd + 1] * inv),
+                            pack2bf(oacc[mt][4 * qd + 2] * inv, oacc[mt][4 * qd + 3] * inv)};
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// MODE 7: 8 waves on 128 rows -- 4 row groups x 2 key halves like the product kernel (balanced for causal calls: 128-row units),
+// but WITHOUT loader waves (DMA from the compute waves, 4 pieces per wave and tile), ONE barrier per tile, and the key-half-1
+// waves (the SIMD partners) rotated by one phase.  Unpadded swizzled images as in the 4-wave form; 3 stages of 32 KB.
+template <int DUMMYARG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn8h_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int ntiles, float sc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
+  const int rg = wave & 3, kh = wave >> 2;
+  const int row0 = blockIdx.x * 128 + rg * 32;
+  const unsigned int lds_base = (unsigned int)(size_t)smem;
+  // DMA: wave w takes K chunks c = (w & 3) + 4 j for j = 2 (w >> 2) .. + 1, and the same V chunks
+  const int r_in = lane >> 4, pp = lane & 15;
+  const unsigned int k_src = (unsigned int)(r_in * 256 + ((pp ^ (4 * (wave & 3) + r_in)) << 4));
+  const unsigned int v_src = (unsigned int)(r_in * 256 + (((((pp >> 2) ^ r_in) << 2) | (pp & 3)) << 4));
+  auto dma_tile = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = (wave & 3) + 4 * (2 * (wave >> 2) + j);
+#pragma unroll
+      for (int isv = 0; isv < 2; ++isv) {
+        const unsigned char* base = (const unsigned char*)(isv ? v : k) + (size_t)c * 1024;
+        const unsigned int dst = lds_base + (unsigned int)st * STAGE4 + (isv ? 16384u : 0u) + 1024u * c;
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(isv ? v_src : k_src), "s"(dst), "s"(base) : "memory");
+      }
+    }
+  };
+  u32x4 qf[8];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(q + (size_t)(row0 + l31) * D + 16 * kd + 8 * hi5);
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) asm volatile("" : "+v"(qf[kd]));
+  f32x16 oacc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  dma_tile(0);
+  dma_tile(1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  const unsigned int k_base = (unsigned int)((32 * kh + l31) * 256 + ((l15 >> 1) << 5) + ((hi5 ^ (l15 & 1)) << 4));
+  const unsigned int v_base = (unsigned int)(16384 + (32 * kh + 4 * hi5 + (l15 >> 2)) * 256 + ((l15 >> 2) << 6) + 32 * ((lane >> 4) & 1) + 8 * (l15 & 3));
+  unsigned int ak[8], av[4];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) ak[kd] = k_base ^ (unsigned int)(kd << 5);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) av[mt] = v_base ^ (unsigned int)(mt << 6);
+  auto qk = [&](int st, f32x16& s) {
+    u32x4 fr[8];
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) fr[kd] = *(const u32x4*)(smem + ak[kd] + st * STAGE4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd]), mf(qf[kd]), s, 0, 0, 0);
+  };
+  auto smax = [&](f32x16& s) {
+    float rmax = vmax2(__builtin_fmaxf(s[0], s[1]), s[2]);
+    rmax = vmax2(rmax, s[3]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) rmax = vmax3(rmax, s[r], s[r + 1]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    if (__any(m_new > m_run + 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+  };
+  auto sexp = [&](f32x16& s, u32x4 (&pf)[2]) {
+    const float mu = m_run;
+    float rsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc, -mu));
+      s[r] = p;
+      rsum += p;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      pf[ks] = u32x4{pack2bf(s[8 * ks + 0], s[8 * ks + 1]), pack2bf(s[8 * ks + 2], s[8 * ks + 3]),
+                     pack2bf(s[8 * ks + 4], s[8 * ks + 5]), pack2bf(s[8 * ks + 6], s[8 * ks + 7])};
+    l_run += rsum;
+  };
+  auto pv = [&](int st, const u32x4 (&pf)[2]) {
+    u32x4 fv[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const unsigned char* vp = smem + av[mt] + st * STAGE4 + 16 * ks * 256;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * 256));
+        u32x2 w0, w1;
+        __builtin_memcpy(&w0, &a0, 8);
+        __builtin_memcpy(&w1, &a1, 8);
+        fv[ks][mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fv[ks][mt]), mf(pf[ks]), oacc[mt], 0, 0, 0);
+  };
+  auto tile_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x16 sA, sB;
+  u32x4 pA[2];
+  // stage of tile t = t % 3; three explicit bodies so that every LDS offset is an immediate
+  if (kh == 0) {
+    auto body = [&](auto st_tag) {
+      constexpr int ST = decltype(st_tag)::value;
+      qk(ST, sA);
+      smax(sA);
+      dma_tile((ST + 2) % 3);
+      sexp(sA, pA);
+      pv(ST, pA);
+      tile_barrier();
+    };
+    for (int t = 0; t < ntiles; t += 3) {
+      body(std::integral_constant<int, 0>{});
+      if (t + 1 < ntiles) body(std::integral_constant<int, 1>{});
+      if (t + 2 < ntiles) body(std::integral_constant<int, 2>{});
+    }
+  } else {
+    qk(0, sA);
+    auto body = [&](auto st_tag, f32x16& cur, f32x16& nxt) {
+      constexpr int ST = decltype(st_tag)::value;
+      smax(cur);
+      dma_tile((ST + 2) % 3);
+      sexp(cur, pA);
+      pv(ST, pA);
+      qk((ST + 1) % 3, nxt);
+      tile_barrier();
+    };
+    for (int t = 0; t < ntiles; t += 6) {
+      body(std::integral_constant<int, 0>{}, sA, sB);
+      if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, sB, sA);
+      if (t + 2 < ntiles) body(std::integral_constant<int, 2>{}, sA, sB);
+      if (t + 3 < ntiles) body(std::integral_constant<int, 0>{}, sB, sA);
+      if (t + 4 < ntiles) body(std::integral_constant<int, 1>{}, sA, sB);
+      if (t + 5 < ntiles) body(std::integral_constant<int, 2>{}, sB, sA);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // merge of the key halves through LDS (stage 0 is free behind the last barrier... keep it simple: one more barrier)
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  __syncthreads();
+  float* img = (float*)smem + (size_t)(rg * 32 + l31) * 132 + 4 * hi5;          // row stride 528 B
+  float* ml = (float*)(smem + 128 * 528) + (rg * 32 + l31) * 2;
+  if (kh == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[32 * mt + 8 * qd + e] = oacc[mt][4 * qd + e];
+    if (hi5 == 0) { ml[0] = m_run; ml[1] = l_run; }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const float m1 = ml[0], l1 = ml[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    const float inv = 1.0f / (l_run * a0 + l1 * a1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (oacc[mt][4 * qd + e] * a0 + img[32 * mt + 8 * qd + e] * a1) * inv;
+        bf16_t* op = o + (size_t)(row0 + l31) * D + 32 * mt + 8 * qd + 4 * hi5;
+        *(u32x2*)op = u32x2{pack2bf(x[0], x[1]), pack2bf(x[2], x[3])};
+      }
+  }
+}
 extern "C" int attn8_proto_launch(const void* q, const void* k, const void* v, void* o, int rows, int ntiles, float sc, int mode, void* stream) {
   dim3 grid(rows / 256), block(512);
 #define GO(M) { (void)hipFuncSetAttribute((const void*)attn8_proto<M>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
     hipLaunchKernelGGL((attn8_proto<M>), grid, block, LDS_BYTES, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc); }
-  if (mode == 0) GO(0) else if (mode == 1) GO(1) else GO(2)
+  if (mode == 5 || mode == 6) {         // 4-wave form: 5 = 64 KB of LDS (two workgroups per CU), 6 = 96 KB (one per CU)
+    const int lds = mode == 5 ? 2 * STAGE4 : 3 * STAGE4;
+    (void)hipFuncSetAttribute((const void*)attn4_proto<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn4_proto<2>), dim3(rows / 128), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+    return (int)hipGetLastError();
+  }
+  if (mode == 7) {
+    const int lds = 3 * STAGE4;
+    (void)hipFuncSetAttribute((const void*)attn8h_proto<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((attn8h_proto<0>), dim3(rows / 128), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+    return (int)hipGetLastError();
+  }
+  if (mode == 0) GO(0) else if (mode == 1) GO(1) else if (mode == 3) GO(3) else GO(4)
   return (int)hipGetLastError();
 }
