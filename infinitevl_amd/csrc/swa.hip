@@ -479,594 +479,51 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Prefill kernel (T > 64 query rows per head): 8 wavefronts = 4 row groups x 2 key halves on v_mfma_f32_32x32x16_bf16.
+// Prefill kernel (T > 64 query rows per head): 8 compute wavefronts = 4 row groups x 2 key halves on v_mfma_f32_32x32x16_bf16,
+// plus 4 loader wavefronts.
 //   workgroup : 128 query rows of one head x a range of 64-key tiles; wave (rg, kh) owns rows 32 rg .. 32 rg + 31 and
 //               keys 32 kh .. 32 kh + 31 of every tile, with its OWN online-softmax state (m, l, O^T); the two key halves
 //               of a row group are merged once, through LDS, when the tile loop ends (an in-workgroup split-KV).
 //   why       : a 32x32x16 A fragment (1 KB of LDS) feeds 16 K MAC, twice the 16x16x32 one - the 64-row kernel above
 //               keeps the LDS array busy 768 clk per tile for 544 clk of MFMA per SIMD; 128 rows at 32 per wave give the
-//               same parallelism (workgroups per call) as 16-row waves with half the LDS bytes per MFMA, and the two
-//               waves of one SIMD come from the same workgroup (one barrier per tile, K/V double-buffered in LDS).
-//   S^T = K Q^T : A = K rows (ds_read_b128, rows padded to 272 B), B = Q^T in registers; lane
-//               (row = l & 31, hi = l >> 5) receives the scores of keys (r & 3) + 8 (r >> 2) + 4 hi, r = 0..15.
+//               same parallelism (workgroups per call) as 16-row waves with half the LDS bytes per MFMA.
+//   S^T = K Q^T : A = K rows (ds_read_b128), B = Q^T in registers; lane (row = l & 31, hi = l >> 5) receives the scores of
+//               keys (r & 3) + 8 (r >> 2) + 4 hi, r = 0..15.
 //   O^T = V^T P^T : the MFMA k-slot 8 hi + j of key step ks carries key 16 ks + 8 (j >> 2) + 4 hi + (j & 3): exactly
 //               the order of the lane's own score registers r = 8 ks + j, so P^T is packed in place (no lane exchange);
-//               V^T fragments come from ds_read_b64_tr_b16 on a [64 keys][128 d] image with a 320-byte row stride
-//               (4 rows x 64 B per LDS cycle on distinct banks).
+//               V^T fragments come from ds_read_b64_tr_b16.
 //   epilogue  : key-half 1 parks (m, l, O) in LDS, key-half 0 merges and writes the finished rows back, then all 512
-//               threads store whole rows (256 B of bf16 or 512 B of fp32 partials per row, coalesced).
-constexpr int PF_QT = 128;
-constexpr int PF_THREADS = 768;                                  // 8 compute wavefronts + 4 loader wavefronts (3 per SIMD)
-constexpr int PF_VSTRIDE = 320;
-constexpr int PF_KSTRIDE = 272;                                  // K rows padded by 16 B: the 32-row ds_read_b128 pattern of
-                                                                 // the 32x32x16 A fragment is conflict-free, offsets are immediates
-constexpr int PF_STAGES = 3;                                     // the loaders run up to two tiles ahead of the compute waves
-constexpr int PF_K_BYTES = SWA_KT * PF_KSTRIDE;                  // 17 KB per K stage
-constexpr int PF_V_BYTES = SWA_KT * PF_VSTRIDE;                  // 20 KB per V stage
-constexpr int PF_V_OFF = PF_STAGES * PF_K_BYTES;
-constexpr int PF_LDS_BYTES = PF_V_OFF + PF_STAGES * PF_V_BYTES;  // 111 KB
-constexpr int PF_OSTRIDE = 528;                                  // bytes per merged fp32 row (512 + 16: bank shift per row)
-constexpr int PF_ML_OFF = 4 * 32 * PF_OSTRIDE;                   // (m, l) pairs behind the four 32-row images
-static_assert(PF_ML_OFF + 128 * 8 <= PF_LDS_BYTES, "merge image must fit the K/V stages");
-
-__global__ __launch_bounds__(PF_THREADS, 1) void swa_prefill_kernel(SwaParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PF_LDS_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
-  const bool loader = wave >= 8;
-  const int rg = wave & 3, kh = (wave >> 2) & 1;
-  // same XCD-aware block order as swa_fwd_kernel: logical ids (b, split, head, q-tile), heads of one kv group adjacent
-  int bx, rest;
-  {
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qn = nwg >> 3, rn = nwg & 7;
-    if (rn == 0 && qn % p.n_qtiles == 0) {
-      const int hx = qn / p.n_qtiles;
-      const int r = slot / hx, half = (p.n_qtiles + 1) >> 1;
-      bx = qn > 32 ? p.n_qtiles - 1 - r : (r < half ? p.n_qtiles - 1 - r : r - half);
-      rest = xcd * hx + slot % hx;
-    } else {
-      const int lid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-      bx = lid % p.n_qtiles;
-      rest = lid / p.n_qtiles;
-    }
-  }
-  const int G = p.Hq / p.Hkv;
-  const int hq = rest % p.Hq, bz = rest / p.Hq;
-  const int b = bz / p.nsplit, split = bz % p.nsplit;
-  const int hk = hq / G;
-  IVL_T(tr_start);
-#ifdef IVL_TRACE
-  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
-  const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
-  const int n_prev = n_ring + (p.T_new - p.T);
-  const int S = n_prev + p.T;
-  const int s0 = p.C > 0 ? mod_pos(pos - n_ring, p.C) : 0;
-
-  const int tile_row0 = bx * PF_QT;
-  // workgroup key-tile range
-  const int last_row = min(tile_row0 + PF_QT, p.T) - 1;
-  const int lo_min = p.W > 0 ? max(0, n_prev + tile_row0 - p.W + 1) : 0;
-  const int kt0 = lo_min / SWA_KT, kt1 = (n_prev + last_row) / SWA_KT + 1;
-  const int per = (kt1 - kt0 + p.nsplit - 1) / p.nsplit;
-  const int kt_begin = kt0 + split * per;
-  const int kt_end = min(kt1, kt_begin + per);
-  const int n = kt_end - kt_begin;            // workgroup-uniform
-
-  // barrier between two segments of the tile loop: LDS stores of the segment are visible behind it; global loads stay in
-  // flight across it (no vmcnt wait), and no instruction is scheduled across it
-  auto seg_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // Segments sigma = 0 .. 2n, each closed by a barrier (after one barrier that publishes tile 0):
-  //   key half 0 :  A(t) = K fragments, S = K Q^T, row max      at sigma = 2t       B(t) = V^T fragments, exponentials,
-  //   key half 1 :  the same code ONE SEGMENT LATER (2t + 1, 2t + 2)                        O^T += V^T P^T   at 2t + 1
-  //   loaders    :  sigma = 2t: K(t+1) -> LDS over K(t-1) (last read at 2t - 1), loads of K(t+3) put in flight
-  //                 sigma = 2t + 1: V(t+1) -> LDS over V(t-1) (last read at 2t), loads of V(t+3) put in flight
-  // so the MFMA chain of one compute wave always faces the VALU-bound softmax of its SIMD partner, and no compute wave
-  // ever waits for a global load or issues an LDS store inside the loop.
-  if (loader) {
-    // ---- loader wavefronts: waves 8, 9 stage K, waves 10, 11 stage V, by LDS-DMA (global_load_lds_dwordx4: 1 KB of LDS per
-    //      wave-instruction, lane l -> bytes 16 l .. 16 l + 15 of the chunk).  The padded images are covered chunk by chunk:
-    //      16-byte piece q = 64 chunk + lane of the K image is (row q / 17, column q % 17), of the V image (q / 20, q % 20);
-    //      column 16.. is padding (the lane fetches a harmless address).  No data registers, no ds_write, and nothing for
-    //      the compiler to wait on: completion is a counted s_waitcnt vmcnt before the barrier that publishes the tile. ------
-   auto loader_body = [&](auto is_k_tag) {
-    constexpr bool is_k = decltype(is_k_tag)::value;
-    constexpr int PPR = is_k ? PF_KSTRIDE / 16 : PF_VSTRIDE / 16;        // 16-byte pieces per image row (17 | 20)
-    const int chunk0 = is_k ? (wave == 8 ? 0 : 9) : (wave == 10 ? 0 : 10);
-    const int nch = is_k ? (wave == 8 ? 9 : 8) : 10;                      // chunks of this wave
-    const long long ring_off = p.C > 0 ? (((long long)b * p.Hkv + hk) * p.C) * SWA_D : 0;
-    const long long n_sb = is_k ? p.kn_sb : p.vn_sb, n_st = is_k ? p.kn_st : p.vn_st, n_sh = is_k ? p.kn_sh : p.vn_sh;
-    const long long new_off = (long long)b * n_sb + (long long)hk * n_sh;
-    const bf16_t* const b_ring = p.C > 0 ? (is_k ? p.k_cache : p.v_cache) + ring_off : (is_k ? p.k_new : p.v_new);
-    const bf16_t* const b_new = (is_k ? p.k_new : p.v_new) + new_off;
-    const unsigned int kn_st32 = (unsigned int)n_st;
-    const long long rplane = (long long)p.B * p.T * SWA_D;
-    const bf16_t* const rope_cos = p.rcos + (long long)b * p.T * SWA_D;
-    const bf16_t* const rope_sin = p.rsin + (long long)b * p.T * SWA_D;
-    // per-lane byte offset of the chunk's piece in a 64-row tile (recomputed per instruction: a table of them ends up in scratch)
-    auto piece_off = [&](int c, bool ring) -> unsigned int {
-      const int q = 64 * (chunk0 + c) + lane;
-      const int r = q / PPR, col = q % PPR;
-      const bool pad = col >= 16 || r >= SWA_KT;
-      return pad ? 0u : (ring ? (unsigned int)(r * SWA_D * 2 + col * 16) : (unsigned int)r * kn_st32 * 2 + col * 16);
-    };
-
-    const unsigned int img0 = is_k ? 0u : (unsigned int)PF_V_OFF;
-    const unsigned int img_bytes = is_k ? (unsigned int)PF_K_BYTES : (unsigned int)PF_V_BYTES;
-    // Tile kinds (wave-uniform): 64 consecutive ring slots | 64 already-rotated keys of this call -> DMA; anything else
-    // (ring wrap, ring / new seam, tail, un-rotated new keys) -> loaded through registers, fixed up and stored
-    // synchronously (slow_store): the loaders run up to two tiles ahead of the compute waves, which absorbs it.
-    auto tile_kind = [&](int kt, bool& ring_fast) -> bool {
-      const int j0 = kt * SWA_KT, slot0 = s0 + j0;
-      ring_fast = j0 + SWA_KT <= n_ring && (slot0 + SWA_KT <= p.C || slot0 >= p.C);
-      const bool new_fast = j0 >= n_ring && j0 + SWA_KT <= S && !(is_k && p.rcos != nullptr);
-      return ring_fast || new_fast;
-    };
-    auto dma_tile = [&](int kt, int st, bool ring_fast, int c_lo, int c_hi) {
-      const int j0 = kt * SWA_KT, slot0 = s0 + j0;
-      const unsigned long long base_u = ring_fast
-          ? (unsigned long long)(b_ring + (long long)(slot0 >= p.C ? slot0 - p.C : slot0) * SWA_D)
-          : (unsigned long long)(b_new + (long long)(j0 - n_ring) * n_st);
-      const unsigned char* const base = (const unsigned char*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(base_u >> 32)) << 32) |
-                                                               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)base_u));
-      const unsigned int lds0 = (unsigned int)(size_t)smem + img0 + (unsigned int)st * img_bytes + (unsigned int)chunk0 * 1024u;
-#define PF_DMA(c)                                                                                                         \
-      if (c >= c_lo && c < c_hi) {                                                                                                      \
-        unsigned int keep;                                                                                                \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"       \
-                     : "=&s"(keep) : "v"(piece_off(c, ring_fast)), "s"(lds0 + 1024u * c), "s"(base) : "memory");           \
-      }
-      PF_DMA(0) PF_DMA(1) PF_DMA(2) PF_DMA(3) PF_DMA(4) PF_DMA(5) PF_DMA(6) PF_DMA(7) PF_DMA(8) PF_DMA(9)
-#undef PF_DMA
-    };
-    // slow tile: clamped per-row loads from both sources, zero rows past the end, rope of the call's keys, LDS stores.
-    // 128 lanes: K: lane -> rows (L >> 3) + 16 i (i < 4), the chunk pair (c, c + 8) (both halves of a rope pair);
-    // V: rows (L >> 4) + 8 i (i < 8), chunk L & 15.
-    const int L = (tid - 512) & 127;
-    auto slow_store = [&](int kt, int st) {
-      const int kc = L & 7, row0 = is_k ? L >> 3 : L >> 4, RS = is_k ? 16 : 8;
-      const unsigned int ch_off = is_k ? kc * 8 : (L & 15) * 8;
-      const int j0 = kt * SWA_KT;
-      u32x4 r[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ri = is_k ? i >> 1 : i;                         // row index of this piece
-        const int j = j0 + row0 + RS * ri;
-        const int jc = min(j, S - 1);
-        int slot = s0 + min(jc, max(n_ring - 1, 0));
-        slot = slot >= p.C ? slot - p.C : slot;
-        const unsigned int co = ch_off + (is_k && (i & 1) ? 64u : 0u);
-        const u32x4 a0 = *(const u32x4*)(b_ring + ((unsigned int)slot * SWA_D + co));
-        const u32x4 c0 = *(const u32x4*)(b_new + ((unsigned int)max(jc - n_ring, 0) * kn_st32 + co));
-        r[i] = j < S ? (jc < n_ring ? a0 : c0) : u32x4{0u, 0u, 0u, 0u};
-      }
-      if (is_k && p.rcos != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int jn = min(j0 + row0 + RS * i, S - 1) - n_ring;
-          if (jn >= 0) rope_pair(r[2 * i], r[2 * i + 1], rope_cos, rope_sin, rplane, (long long)jn * SWA_D, kc * 8, p.rs0, p.rs1);
-          if (i & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (is_k) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned char* rowp = smem + st * PF_K_BYTES + (row0 + 16 * i) * PF_KSTRIDE + kc * 16;
-          *(u32x4*)rowp = r[2 * i];
-          *(u32x4*)(rowp + 128) = r[2 * i + 1];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          *(u32x4*)(smem + PF_V_OFF + st * PF_V_BYTES + (row0 + 8 * i) * PF_VSTRIDE + (L & 15) * 16) = r[i];
-      }
-    };
-    // tile of 64 un-rotated keys of this call (fused M-RoPE, K loaders only): the 8 key pieces and the 16 cos / sin pieces of
-    // the lane's four rows are requested together (one memory round trip), rotated and stored
-    auto rope_tile_store = [&](int kt, int st) {
-      const int kc = L & 7, row0 = L >> 3;
-      const int jn0 = kt * SWA_KT - n_ring + row0;                     // index among the call's keys, rows jn0 + 16 i
-      u32x4 lo[4], hi[4], c1[4], n1[4], c2[4], n2[4];
-      const int c0 = kc * 8;
-      const int sec = c0 < p.rs0 ? 0 : (c0 < p.rs0 + p.rs1 ? 1 : 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned int ko = (unsigned int)(jn0 + 16 * i) * kn_st32 + c0;
-        lo[i] = *(const u32x4*)(b_new + ko);
-        hi[i] = *(const u32x4*)(b_new + (ko + 64));
-        const long long off = sec * rplane + (long long)(jn0 + 16 * i) * SWA_D + c0;
-        c1[i] = *(const u32x4*)(rope_cos + off); n1[i] = *(const u32x4*)(rope_sin + off);
-        c2[i] = *(const u32x4*)(rope_cos + off + 64); n2[i] = *(const u32x4*)(rope_sin + off + 64);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rope_apply(lo[i], hi[i], c1[i], n1[i], c2[i], n2[i]);
-        unsigned char* rowp = smem + st * PF_K_BYTES + (row0 + 16 * i) * PF_KSTRIDE + kc * 16;
-        *(u32x4*)rowp = lo[i];
-        *(u32x4*)(rowp + 128) = hi[i];
-      }
-    };
-    // tile i of the workgroup's range into stage i % 3, in two parts (part 0: the first PF_H1 DMA instructions, or the whole
-    // tile when it takes the register path; part 1: the rest); returns true when part 0 issued DMA instructions
-    constexpr int PF_H1 = 5;
-    auto fetch = [&](int i, int part) -> bool {
-      if (i >= n) return false;
-      bool rf;
-      const int st = i % PF_STAGES;
-      if (tile_kind(kt_begin + i, rf)) {
-        if (part == 0) dma_tile(kt_begin + i, st, rf, 0, PF_H1);
-        else dma_tile(kt_begin + i, st, rf, PF_H1, nch);
-        return true;
-      }
-      if (part == 0) {
-        const int j0 = (kt_begin + i) * SWA_KT;
-        if (is_k && p.rcos != nullptr && j0 >= n_ring && j0 + SWA_KT <= S) rope_tile_store(kt_begin + i, st);
-        else slow_store(kt_begin + i, st);
-      }
-      return false;
-    };
-    // everything issued before part 0 of the newest tile (`newest_dma`: its PF_H1 instructions may stay in flight) has landed
-    auto wait_older = [&](bool newest_dma) {
-      if (!newest_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    };
-    static_assert(PF_H1 == 5, "wait_older counts PF_H1 instructions");
-    IVL_TVAR(tl_k); IVL_TVAR(tl_kw); IVL_TVAR(tl_v); IVL_TVAR(tl_vw);
-    IVL_T(tl_s0);
-    // ONE loop for the start-up and the steady state (each part of `fetch` is instantiated once per loader kind: the kernel
-    // is larger than the 64 KB instruction cache two CUs share, and the start-up ran through cold code -- ~6,000 cycles before
-    // the first DMA instruction).  Iterations j = -2, -1 issue what the steady state would have issued two tiles earlier,
-    // without the barriers; the compute waves start behind the start-up barrier, which needs K(0) only (behind j = -2).
-    // K(i): stage free from segment 2i - 4, complete before barrier 2i - 1: issued in segments 2i - 4 | 2i - 3, waited for in 2i - 1.
-    // V(i): free from 2i - 3, complete before barrier 2i: issued in segments 2i - 3 | 2i - 2, waited for in 2i.
-    bool newest = false;
-#pragma nounroll
-    for (int j = -2; j < n; ++j) {
-      IVL_T(tl0);
-      if (is_k) {
-        newest = fetch(j + 2, 0);               // K(j+2) over K(j-1), last read before barrier 2j - 1
-      } else {
-        if (j >= 0) wait_older(newest);         // V(j) has landed (part 0 of V(j+1) may still fly)
-        if (j >= -1) fetch(j + 1, 1);
-      }
-      IVL_T(tl1);
-      if (j >= 0) seg_barrier();                // sigma = 2j
-      IVL_T(tl2);
-      if (is_k) {
-        if (j >= 0) wait_older(newest);         // K(j+1) has landed
-        fetch(j + 2, 1);
-      } else {
-        newest = fetch(j + 2, 0);               // V(j+2) over V(j-1), last read before barrier 2j
-      }
-      IVL_T(tl3);
-      if (j >= 0) seg_barrier();                // sigma = 2j + 1
-      IVL_T(tl4);
-      if (j == -2) {
-        if (is_k) wait_older(false);            // K(0) is in LDS (K(1), V(0) follow: before barriers 1 and 0)
-        IVL_T(tl_s2);
-        seg_barrier();                          // the compute waves start
-        IVL_TOUT_AT(512, 41, tl_s0 - tr_start); IVL_TOUT_AT(512, 43, tl_s2 - tl_s0);
-        IVL_TOUT_AT(640, 49, tl_s2 - tl_s0);
-      }
-      if (j >= 0) {
-        IVL_TACC(tl_k, tl1, tl0); IVL_TACC(tl_kw, tl2, tl1); IVL_TACC(tl_v, tl3, tl2); IVL_TACC(tl_vw, tl4, tl3);
-      }
-    }
-    seg_barrier();                              // sigma = 2n
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IVL_TOUT_AT(512, 55, tl_k); IVL_TOUT_AT(512, 56, tl_kw); IVL_TOUT_AT(512, 59, tl_v); IVL_TOUT_AT(512, 60, tl_vw);
-    IVL_TOUT_AT(640, 57, tl_k); IVL_TOUT_AT(640, 58, tl_kw); IVL_TOUT_AT(640, 62, tl_v); IVL_TOUT_AT(640, 63, tl_vw);
-   };
-   if (wave < 10) loader_body(std::true_type{});
-   else loader_body(std::false_type{});
-  } else {
-    // ---- compute wavefronts ------------------------------------------------------------------------------------------
-    const int row = tile_row0 + 32 * rg + l31;
-    const bool row_ok = row < p.T;
-    const int band_hi = n_prev + row;
-    const int band_lo = p.W > 0 ? max(0, n_prev + row - p.W + 1) : 0;
-    // band extremes of this wave's 32 rows (lo / hi are monotone in the row)
-    const int wr0 = tile_row0 + 32 * rg, wr1 = max(min(wr0 + 31, p.T - 1), wr0);
-    const int w_hi_min = n_prev + wr0, w_hi_max = n_prev + wr1;
-    const int w_lo_min = p.W > 0 ? max(0, n_prev + wr0 - p.W + 1) : 0;
-    const int w_lo_max = p.W > 0 ? max(0, n_prev + wr1 - p.W + 1) : 0;
-
-    // Q^T fragments (B operand): lane = query row, d = 16 kd + 8 hi .. +7
-    u32x4 qf[8];
-    {
-      const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(row, p.T - 1) * p.q_st + (long long)hq * p.q_sh;
-#pragma unroll
-      for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qp + 16 * kd + 8 * hi5);
-    }
-    if (p.rcos != nullptr) {
-      // fused M-RoPE of the query tile: the sixteen table pieces of the lane's row are requested together with its eight query
-      // pieces (one memory round trip), then rotated in registers -- while the loaders bring the first key tile in
-      const long long row_off = ((long long)b * p.T + min(row, p.T - 1)) * SWA_D;
-      const long long plane = (long long)p.B * p.T * SWA_D;
-      u32x4 c1[4], n1[4], c2[4], n2[4];
-#pragma unroll
-      for (int kd = 0; kd < 4; ++kd) {
-        const int c0 = 16 * kd + 8 * hi5;
-        const int sec = c0 < p.rs0 ? 0 : (c0 < p.rs0 + p.rs1 ? 1 : 2);
-        const long long off = sec * plane + row_off + c0;
-        c1[kd] = *(const u32x4*)(p.rcos + off); n1[kd] = *(const u32x4*)(p.rsin + off);
-        c2[kd] = *(const u32x4*)(p.rcos + off + 64); n2[kd] = *(const u32x4*)(p.rsin + off + 64);
-      }
-#pragma unroll
-      for (int kd = 0; kd < 4; ++kd) rope_apply(qf[kd], qf[kd + 4], c1[kd], n1[kd], c2[kd], n2[kd]);
-    }
-    if (!row_ok) {
-#pragma unroll
-      for (int kd = 0; kd < 8; ++kd) qf[kd] = u32x4{0u, 0u, 0u, 0u};
-    }
-    float m_run = -INFINITY, l_run = 0.f;     // l_run: this LANE's part of the row sum (its 16 keys of every tile)
-    f32x16 oacc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-
-    const float sc = p.scaling * LOG2E;
-    // per-lane LDS offsets: K fragment row (32 kh + l31), V^T fragment block rows / columns
-    const int k_row_off = (32 * kh + l31) * PF_KSTRIDE + 16 * hi5;
-    const int v_off = PF_V_OFF + (32 * kh + 4 * hi5 + (l15 >> 2)) * PF_VSTRIDE + (16 * ((lane >> 4) & 1) + 4 * (l15 & 3)) * 2;
-    auto is_dead = [&](int kt) {                // no row of the wave sees any of its 32 keys of tile kt
-      const int kbeg = kt * SWA_KT + 32 * kh;
-      return kbeg > w_hi_max || kbeg + 31 < w_lo_min;
-    };
-    u32x4 fr[8], pf[2];       // K fragments and V^T fragments time-share one register block
-    float m_use = 0.f, alpha = 1.f;
-    bool need = false;
-    f32x16 sacc;
-    auto row_max = [&](int kt) {      // band mask, running max, rescale factor
-      const int kbeg = kt * SWA_KT + 32 * kh;
-      const bool interior = kbeg >= w_lo_max && kbeg + 31 <= w_hi_min;
-      if (!interior) {
-        const int jb = kbeg + 4 * hi5;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = jb + (r & 3) + 8 * (r >> 2);
-          const bool vis = row_ok && j >= band_lo && j <= band_hi;
-          sacc[r] = vis ? sacc[r] : -INFINITY;
-        }
-      }
-      // first reader of the MFMA results = an instruction the compiler sees (see swa_fwd_kernel): hazard wait states
-      float rmax = vmax2(__builtin_fmaxf(sacc[0], sacc[1]), sacc[2]);
-      rmax = vmax3(rmax, sacc[3], sacc[4]);
-      rmax = vmax3(rmax, sacc[5], sacc[6]);
-      rmax = vmax3(rmax, sacc[7], sacc[8]);
-      rmax = vmax3(rmax, sacc[9], sacc[10]);
-      rmax = vmax3(rmax, sacc[11], sacc[12]);
-      rmax = vmax3(rmax, sacc[13], sacc[14]);
-      rmax = vmax2(rmax, sacc[15]);
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
-      rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
-      const float m_new = vmax2(m_run, rmax);
-      // LAZY reference: m_run is the exponent reference of the row, not its exact running maximum.  It follows the maximum
-      // only when some row of the wave has outgrown it by more than 2^8 (always on a row's first visible tile: -inf + 8 =
-      // -inf); until then the probabilities are 2^(s - m_run) <= 2^8 - exact in fp32 and of the same relative precision in
-      // bf16 - and the accumulators need no rescale: 33 v_pk_mul_f32 per wave and tile (10 % of the tile's VALU issue)
-      // behind a wave-uniform branch that is taken a handful of times per call.  (m, l, O) stay consistent: the merge of the
-      // key halves and the split-KV combine use m_run as the partial's reference.
-      need = __any(m_new > m_run + 8.0f);
-      if (need) {
-        const float m_u = m_new == -INFINITY ? 0.f : m_new;
-        alpha = __builtin_amdgcn_exp2f(m_run - m_u);     // exact rescale of every row of the wave to its own maximum
-#pragma unroll
-        for (int i = 0; i < 4; ++i) oacc[i] *= alpha;
-        l_run *= alpha;
-        m_run = m_new;
-      }
-      m_use = m_run == -INFINITY ? 0.f : m_run;
-    };
-    auto exps = [&]() {                  // probabilities, row-sum part, P^T fragments
-      float rsum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sc, -m_use));
-        sacc[r] = pv;
-        rsum += pv;
-      }
-      l_run += rsum;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        pf[ks].x = pack2bf(sacc[8 * ks + 0], sacc[8 * ks + 1]);
-        pf[ks].y = pack2bf(sacc[8 * ks + 2], sacc[8 * ks + 3]);
-        pf[ks].z = pack2bf(sacc[8 * ks + 4], sacc[8 * ks + 5]);
-        pf[ks].w = pack2bf(sacc[8 * ks + 6], sacc[8 * ks + 7]);
-      }
-    };
-    auto qk = [&](int kbuf) {
-#pragma unroll
-      for (int kd = 0; kd < 8; ++kd)
-        fr[kd] = *(const u32x4*)(smem + kbuf * PF_K_BYTES + k_row_off + 32 * kd);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-      for (int kd = 0; kd < 8; ++kd) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[kd]), as_mfma(qf[kd]), sacc, 0, 0, 0);
-    };
-    auto read_v = [&](int vbuf) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-          const unsigned char* vp = smem + vbuf * PF_V_BYTES + v_off + 16 * ks * PF_VSTRIDE + 64 * mt;
-          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
-          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * PF_VSTRIDE));
-          u32x2 w0, w1;
-          __builtin_memcpy(&w0, &a0, 8);
-          __builtin_memcpy(&w1, &a1, 8);
-          fr[4 * ks + mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
-        }
-    };
-    auto pv = [&]() {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)       // consecutive MFMAs on different accumulators
-          oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[4 * ks + mt]), as_mfma(pf[ks]), oacc[mt], 0, 0, 0);
-    };
-
-    IVL_T(tr_loop);
-    IVL_TVAR(tr_a); IVL_TVAR(tr_b); IVL_TVAR(tr_wa); IVL_TVAR(tr_wb);
-    seg_barrier();                              // K(0) is in LDS
-    {
-      // the second-dispatched half loses every VALU arbitration against its older SIMD partner: static priority evens it
-      if (kh == 1) __builtin_amdgcn_s_setprio(1);
-      if (kh == 1) seg_barrier();
-      int st = 0;
-      for (int t = 0; t < n; ++t) {
-        const int kt = kt_begin + t;
-        const bool dead = is_dead(kt);
-        IVL_T(tr0);
-        if (!dead) {
-          qk(st);
-          row_max(kt);
-        }
-        IVL_T(tr1);
-        seg_barrier();
-        IVL_T(tr2);
-        if (!dead) {
-          read_v(st);
-          exps();
-          pv();
-        }
-        IVL_T(tr3);
-        seg_barrier();
-        IVL_T(tr4);
-        IVL_TACC(tr_a, tr1, tr0); IVL_TACC(tr_wa, tr2, tr1); IVL_TACC(tr_b, tr3, tr2); IVL_TACC(tr_wb, tr4, tr3);
-        st = st == PF_STAGES - 1 ? 0 : st + 1;
-      }
-      if (kh == 0) seg_barrier();
-    }
-    IVL_T(tr_end);
-
-    // ---- merge the two key halves of every row group through LDS (the K/V stages are free behind the next barrier) --
-    {
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-      l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    __syncthreads();
-    unsigned char* oimg = smem + rg * 32 * PF_OSTRIDE + l31 * PF_OSTRIDE + 16 * hi5;      // + 128 mt + 32 q : d = 32 mt + 8 q + 4 hi
-    float* ml = (float*)(smem + PF_ML_OFF) + (rg * 32 + l31) * 2;
-    if (kh == 1) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f32x4*)(oimg + 128 * mt + 32 * q) = f32x4{oacc[mt][4 * q], oacc[mt][4 * q + 1], oacc[mt][4 * q + 2], oacc[mt][4 * q + 3]};
-      if (hi5 == 0) {
-        ml[0] = m_run;
-        ml[1] = l_run;
-      }
-    }
-    __syncthreads();
-    if (kh == 0) {
-      const float m1 = ml[0], l1 = ml[1];
-      const float m = vmax2(m_run, m1);
-      const float mu = m == -INFINITY ? 0.f : m;
-      const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
-      const float l = l_run * a0 + l1 * a1;
-      const float inv = l > 0.f ? 1.0f / l : 0.f;      // normalised rows also for the split-KV partials (stored in bf16)
-      const float w0 = a0 * inv, w1 = a1 * inv;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 o1 = *(const f32x4*)(oimg + 128 * mt + 32 * q);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = oacc[mt][4 * q + e] * w0 + o1[e] * w1;
-          *(f32x4*)(oimg + 128 * mt + 32 * q) = o;
-        }
-      if (hi5 == 0) {
-        ml[0] = m;
-        ml[1] = l;
-      }
-    }
-    __syncthreads();
-    // ---- whole-row stores by the 512 compute threads: 256 B of bf16 per row, into o or into the split's partial rows ----
-    {
-      bf16_t* const dst = p.nsplit == 1 ? p.o : (bf16_t*)p.part_o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;       // row, 8-channel piece
-        const int t = tile_row0 + r;
-        if (t < p.T) {
-          const unsigned char* src = smem + r * PF_OSTRIDE + c * 32;
-          const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
-          const long long orow = p.nsplit == 1 ? ((long long)b * p.T + t) * p.Hq + hq
-                                               : (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
-          *(u32x4*)(dst + orow * SWA_D + 8 * c) =
-              u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
-        }
-      }
-      if (p.nsplit > 1 && tid < PF_QT && tile_row0 + tid < p.T) {
-        const long long prow = (((long long)b * p.nsplit + split) * p.T + tile_row0 + tid) * p.Hq + hq;
-        *(float2*)(p.part_ml + prow * 2) = *(const float2*)(smem + PF_ML_OFF + tid * 8);
-      }
-    }
-    IVL_T(tr_fin);
-    IVL_TOUT(32, tr_loop - tr_start); IVL_TOUT(38, tr_fin - tr_end); IVL_TOUT(39, tr_fin - tr_start); IVL_TOUT(40, kt_end - kt_begin);
-    IVL_TOUT(42, 1); IVL_TOUT(47, tr_end - tr_loop);
-#ifdef IVL_TRACE
-    // spread of the workgroup durations: slot 44 = max, 45 = min of (cycles << 24 | tiles << 16 | split << 8 | q-tile)
-    if (ivl_trace_buf != nullptr && tid == 0) {
-      const long long v = ((tr_fin - tr_start) << 24) | ((long long)(kt_end - kt_begin) << 16) | ((long long)split << 8) | bx;
-      atomicMax((unsigned long long*)ivl_trace_buf + 44, (unsigned long long)v);
-      atomicMin((unsigned long long*)ivl_trace_buf + 45, (unsigned long long)v);
-      // spread of the launch on the shared 100 MHz clock: first workgroup start (29), last start (31), last end (30)
-      atomicMin((unsigned long long*)ivl_trace_buf + 29, rt_start);
-      atomicMax((unsigned long long*)ivl_trace_buf + 31, rt_start);
-      atomicMax((unsigned long long*)ivl_trace_buf + 30, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
-#endif
-    IVL_TOUT(33, tr_a); IVL_TOUT(34, tr_wa); IVL_TOUT(35, tr_b); IVL_TOUT(36, tr_wb);
-    IVL_TOUT_AT(256, 50, tr_a); IVL_TOUT_AT(256, 51, tr_wa); IVL_TOUT_AT(256, 52, tr_b); IVL_TOUT_AT(256, 53, tr_wb);
-    return;
-  }
-  // loader wavefronts: the three barriers of the merge epilogue
-  __syncthreads();
-  __syncthreads();
-  __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Prefill kernel, round 5: the tile loop rebuilt on the 8-wave structure of cdna_hip_programming.md Appendix B,
-// measured first as a stand-alone prototype (tools/proto/attn8_proto.hip, MODE 7: 894-914 TFLOP/s against 742-760 for the kernel
-// above on the same box).  Same decomposition as above -- 128 query rows of one head, 8 compute waves = 4 row groups x 2 key halves
-// on v_mfma_f32_32x32x16_bf16, lane-local rows, P^T packed in place, key halves merged once at the end -- but:
-//   * NO loader waves: 512 threads, two waves per SIMD with up to 256 VGPRs each.  The compute waves issue the LDS-DMA themselves:
-//     a tile is 2 x 16 one-KB pieces = 4 per wave, issued in the VALU-only stretch between the row maximum and the exponentials
-//     (an LDS-DMA piece costs the issuing wave 25-60 cycles there, 100-185 beside LDS reads: MI355X_MICROARCH.md).
-//   * ONE barrier per tile (16 MFMAs per wave between barriers instead of 8): a 3-stage ring; tile t + 2 is requested during
-//     tile t into the stage tile t - 1 left at the previous barrier, and awaited (counted vmcnt) before the barrier that ends tile t + 1.
+//               compute threads store whole rows (256 B of bf16 per row, coalesced), into o or the split's partial rows.
+// Round 5 rebuilt the tile loop (the round-2 form -- two barrier segments per tile, key half 1 one segment behind,
+// padded images, 37 DMA pieces per tile -- measured 2,400-2,550 cycles per tile; this one 2,100, same-box A/B in DESIGN.md 4.3):
+//   * ONE barrier per tile (16 MFMAs per compute wave between barriers instead of 8): a 4-stage ring; the loaders request tile
+//     t + 3 during tile t into the stage tile t - 1 left at the previous barrier, and arrive at the barrier that ends tile t with
+//     tile t + 2 landed (counted vmcnt) -- the rotated half reads K(t + 1) one barrier early.
 //   * the key-half-1 waves (the SIMD partners of the key-half-0 waves) run their phases ROTATED by one: softmax(t), PV(t), then
 //     QK^T(t + 1) -- the partner's QK^T MFMAs face this wave's softmax VALU and the partner's softmax faces this wave's PV MFMAs
-//     (the round-2 kernel skewed the halves by a barrier segment; with one barrier per tile the skew is in the program order).
+//     -- at static priority 1 (the second-dispatched half loses the VALU arbitration otherwise: MI355X_MICROARCH.md).
 //   * unpadded 64 x 256 B images, XOR-swizzled on the SOURCE side of the DMA (the LDS side of a DMA piece is lane-linear): K
 //     16-byte piece p of row r sits at p ^ (r & 15) (conflict-free for the 32-row ds_read_b128 pattern), V 64-byte granule g of
-//     row r at g ^ (r & 3) (conflict-free for ds_read_b64_tr_b16); a fragment address is base ^ (kd << 5) | base ^ (mt << 6).
-//   * wrap / seam / tail tiles and un-rotated keys of a short fused-rope call go through registers in the compute waves (the
+//     row r at g ^ (r & 3) (conflict-free for ds_read_b64_tr_b16); a fragment address is base ^ (kd << 5) | base ^ (mt << 6);
+//     32 one-KB DMA pieces per tile, 8 per loader wave, none wasted on padding.
+//   * wrap / seam / tail tiles and un-rotated keys of a short fused-rope call go through registers in the loader waves (the
 //     same lane -> (row, piece) map as a DMA piece, so the swizzle is shared): at most three such tiles per 68-tile row.
-// Band, split-KV partial rows, merge epilogue, block order: as above.
+//   * everything derived from the device-resident position is moved to SGPRs (v_readfirstlane): tile kinds and DMA bases are SALU.
+// Measured on the way (tools/proto/attn8_proto.hip): the same loop WITHOUT loader waves (512 threads, 256 VGPRs, the
+// compute waves issuing 4 DMA pieces each between row maximum and exponentials) ran 894-914 TFLOP/s on an L1-resident tile but
+// LOST in the product (3,170 cycles per tile): an LDS-DMA piece blocks its issuing wave for 140-240 cycles when all eight waves
+// of a CU stream real K / V (the CU accepts ~1 KB per 30 cycles) -- the loader waves exist to absorb exactly that.
+constexpr int PF_QT = 128;
+constexpr int PF_OSTRIDE = 528;                                  // bytes per merged fp32 row (512 + 16: bank shift per row)
+constexpr int PF_ML_OFF = 4 * 32 * PF_OSTRIDE;                   // (m, l) pairs behind the four 32-row images
 constexpr int P8_THREADS = 768;                                  // 8 compute wavefronts + 4 loader wavefronts (3 per SIMD: <= 168 VGPRs)
 constexpr int P8_IMG = SWA_KT * 256;                              // 16 KB per image
 constexpr int P8_STAGE = 2 * P8_IMG;                              // K | V
-constexpr int P8_STAGES = 3;
-constexpr int P8_LDS_BYTES = P8_STAGES * P8_STAGE;                // 96 KB
+constexpr int P8_STAGES = 4;                                      // tile t in stage t % 4 (why four: see the loader loop)
+constexpr int P8_LDS_BYTES = P8_STAGES * P8_STAGE;                // 128 KB
 static_assert(PF_ML_OFF + 128 * 8 <= P8_LDS_BYTES, "merge image must fit the K/V stages");
 
-__global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p) {
+__global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill_kernel(SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[P8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
@@ -1202,15 +659,19 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
+    // The rotated key half reads K(t + 1) during tile t, i.e. BEHIND the barrier that ends tile t - 1: the loaders arrive at the
+    // barrier that ends tile t with tile t + 2 landed (not t + 1), which takes a request distance of three tiles and FOUR stages
+    // (tile t + 3 goes into the stage tile t - 1 left at the previous barrier).  [A three-stage version that awaited tile t + 1
+    // only passed every single-process test and failed 4 of 12 two-process runs: the DMA of tile t + 1 was usually, not always,
+    // complete when the rotated half read it.]
     if (n > 0) stage_tile(kt_begin, 0);
     if (n > 1) stage_tile(kt_begin + 1, 1);
-    land(0);                                                              // tiles 0 and 1 are in LDS: the compute waves start
-    int st2 = 2;
+    const int fly2 = n > 2 ? stage_tile(kt_begin + 2, 2) : 0;
+    land(fly2);                                                           // tiles 0 and 1 are in LDS: the compute waves start
 #pragma nounroll
     for (int t = 0; t < n; ++t) {
-      const int fly = t + 2 < n ? stage_tile(kt_begin + t + 2, st2) : 0;
-      land(fly);
-      st2 = st2 == 2 ? 0 : st2 + 1;
+      const int fly = t + 3 < n ? stage_tile(kt_begin + t + 3, (t + 3) & 3) : 0;
+      land(fly);                                                          // tile t + 2 has landed
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                      // the three barriers of the merge epilogue
@@ -1283,7 +744,14 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p
 #pragma unroll
     for (int kd = 0; kd < 8; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_mfma(fr[kd]), as_mfma(qf[kd]), s, 0, 0, 0);
   };
-  auto row_max = [&](int kt, f32x16& s) __attribute__((always_inline)) {     // band mask, lazy exponent reference, rescale (see swa_prefill_kernel)
+  // band mask, running exponent reference, rescale.  LAZY reference: m_run is the exponent reference of the row, not its exact
+  // running maximum.  It follows the maximum only when some row of the wave has outgrown it by more than 2^8 (always on a row's
+  // first visible tile: -inf + 8 = -inf); until then the probabilities are 2^(s - m_run) <= 2^8 -- exact in fp32 and of the same
+  // relative precision in bf16 -- and the accumulators need no rescale: 33 v_pk_mul_f32 per wave and tile behind a wave-uniform
+  // branch that is taken a handful of times per call.  (m, l, O) stay consistent: the merge of the key halves and the split-KV
+  // combine use m_run as the partial's reference.  The first reader of the MFMA results is an instruction the compiler sees
+  // (hazard wait states: see swa_fwd_kernel).
+  auto row_max = [&](int kt, f32x16& s) __attribute__((always_inline)) {
     const int kbeg = kt * SWA_KT + 32 * kh;
     const bool interior = kbeg >= w_lo_max && kbeg + 31 <= w_hi_min;
     if (!interior) {
@@ -1385,11 +853,12 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p
       tile_barrier();
       IVL_T(t4);
       IVL_TACC(tr_c1, t1, t0); IVL_TACC(tr_st, t2, t1); IVL_TACC(tr_c2, t3, t2); IVL_TACC(tr_w, t4, t3);
-      st = st == 2 ? 0 : st + 1;
+      st = (st + 1) & 3;
     }
   } else {
     // key half 1, rotated:  row max(t) | exponentials | PV(t) | QK^T(t + 1) | barrier
-    // (tile t + 1 is complete since the barrier that ended tile t - 1)
+    // (tile t + 1 is complete since the barrier that ended tile t - 1: the loaders run three tiles ahead)
+    __builtin_amdgcn_s_setprio(1);               // the second-dispatched half loses the VALU arbitration against its SIMD partner
     if (n > 0 && !is_dead(kt_begin)) qk(0, sA);
 #pragma nounroll
     for (int t = 0; t < n; ++t) {
@@ -1398,7 +867,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p
       IVL_T(t0);
       if (!dead) row_max(kt, sA);
       IVL_T(t1);
-      const int st1 = st == 2 ? 0 : st + 1;
+      const int st1 = (st + 1) & 3;
       IVL_T(t2);
       if (!dead) {
         exps(sA, pA);
@@ -1414,7 +883,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill8_kernel(SwaParams p
   }
   IVL_T(tr_end);
 
-  // ---- merge the two key halves of every row group through LDS, then whole-row stores (as swa_prefill_kernel) ------------------
+  // ---- merge the two key halves of every row group through LDS (the K/V stages are free behind the next barrier), then whole-row
+  //      stores by the 512 compute threads: 256 B of bf16 per row, into o or into the split's partial rows ----------------------------
   {
     auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -1971,7 +1441,7 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   }
   p.n_qtiles = prefill ? (rows + PF_QT - 1) / PF_QT : (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
-  if (prefill) hipLaunchKernelGGL(swa_prefill8_kernel, grid, dim3(P8_THREADS), 0, st, p);
+  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(P8_THREADS), 0, st, p);
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
     hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
   else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);

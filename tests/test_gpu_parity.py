@@ -2458,3 +2458,42 @@ def test_gdn_concurrent_streams_and_graphs_have_their_own_records():
         for (o, h, so), (ro, rh, rso) in zip(gouts, refs):
             assert torch.equal(o, ro) and torch.equal(h, rh), it
     ops.gdn_sync_check(DEV, deep=True)
+
+
+def test_swa_prefill_is_bit_stable_under_a_co_running_stream():
+    """The prefill kernel's tile ring is filled by LDS-DMA that runs up to three tiles ahead of its readers; every read is ordered
+    behind the landing of its tile by a counted vmcnt + a workgroup barrier, never by timing.  (A version whose rotated key half
+    read a tile one barrier before its landing was guaranteed passed every quiet test and failed 4 of 12 two-process runs.)  So:
+    long and step-shape calls while a second stream keeps the memory system busy with 1 GiB copies and a second stream of
+    attention calls competes for the CUs -- every output and ring equals the quiet run's, bit for bit, 40 times."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d, W = 16, 2, 128, 4096
+    C = W - 1
+    g_ = torch.Generator(device=DEV).manual_seed(77)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    cases = []
+    for T, seen in ((4096, 3 * C + 5), (256, 2 * C + 100), (1000, 17)):
+        q, k, v = rn(1, T, Hq, d), rn(1, T, Hkv, d), rn(1, T, Hkv, d)
+        kc, vc = rn(1, Hkv, C, d), rn(1, Hkv, C, d)
+        cos, sin = _mrope_tables(1, T, seen)
+        pos_dev = torch.full((1,), seen, dtype=torch.int64, device=DEV)
+
+        def run(q=q, k=k, v=v, kc=kc, vc=vc, cos=cos, sin=sin, pos_dev=pos_dev):
+            kc2, vc2 = kc.clone(), vc.clone()
+            o = ops.swa_forward(q, k, v, window=W, scaling=d ** -0.5, k_cache=kc2, v_cache=vc2, pos_dev=pos_dev,
+                                rope=(cos, sin, [16, 24, 24]), append=True)
+            return o, kc2, vc2
+        cases.append((run, run()))
+    torch.cuda.synchronize()
+    a_, b_ = torch.empty(1 << 28, dtype=torch.float32, device=DEV), torch.empty(1 << 28, dtype=torch.float32, device=DEV)
+    noise, other = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(40):
+        with torch.cuda.stream(noise):
+            b_.copy_(a_)
+            a_.copy_(b_)
+        with torch.cuda.stream(other):
+            cases[it % 3][0]()
+        outs = [run() for run, _ in cases]
+        torch.cuda.synchronize()
+        for (o, kc2, vc2), (_, (ro, rk, rv)) in zip(outs, cases):
+            assert torch.equal(o, ro) and torch.equal(kc2, rk) and torch.equal(vc2, rv), it

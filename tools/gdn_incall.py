@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Where do the ~20 us go between the hot micro-benchmark of the long-call GDN launch (T = 4096: 80-87 us) and the same launch
+inside a configs[3] call (100 us)?  (VERDICT r4 #4.)  The launch is timed (profiler activity records) behind four predecessors:
+  hot        : the previous launch of the same call (its inputs are in the L2s / the Infinity Cache)
+  evicted    : a read sweep of 1 GiB in front (inputs come from HBM; nothing of the inputs is dirty)
+  rewritten  : the projection buffer (101 MB) rewritten by a copy kernel in front (what the in-projection GEMM does: the 101 MB
+               are dirty in the writing XCDs' L2s at the kernel boundary and come back from the memory side)
+  gemm       : the projection written by the real [4096 x 2048] x [2048 x 12320] library GEMM in front
+usage: gdn_incall.py [T=4096]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from torch.profiler import ProfilerActivity, profile
+from infinitevl_amd import ops
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda", 0)
+B, H, K, V = 1, 16, 128, 256
+Dq, Dk, Dv = H * K, H * K, H * V
+g_ = torch.Generator(device=dev).manual_seed(1)
+rn = lambda *s: torch.randn(*s, device=dev, generator=g_).to(torch.bfloat16)   # noqa: E731
+cols = (0, Dq, Dq + Dk, Dq + Dk + 2 * Dv, Dq + Dk + 2 * Dv + H)
+ld = cols[4] + H
+cw = [rn(D_, 1, 4) * 0.5 for D_ in (Dq, Dk, Dv)]
+A32, dt32 = torch.randn(H, device=dev, generator=g_), torch.randn(H, device=dev, generator=g_)
+proj, src = rn(B, T, ld), rn(B, T, ld)
+cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
+state = (torch.randn(B, H, K, V, device=dev, generator=g_) * 0.1).to(torch.bfloat16)
+x = rn(B * T, 2048) * 0.05
+w = rn(ld, 2048) * 0.05
+big = torch.empty(1 << 28, dtype=torch.float32, device=dev)          # 1 GiB
+
+
+def gdn():
+    return ops.gdn_chunk_fused(proj, cols, cw, cs, cs, A32, dt32, H, K, V, initial_state=state, final_state_out=state)
+
+
+def pre_hot():
+    pass
+
+
+def pre_evict():
+    big.sum()
+
+
+def pre_rewrite():
+    proj.copy_(src)
+
+
+def pre_gemm():
+    torch.mm(x, w.t(), out=proj.view(B * T, ld))
+
+
+for name, pre in (("hot", pre_hot), ("evicted", pre_evict), ("rewritten", pre_rewrite), ("gemm", pre_gemm)):
+    for _ in range(3):
+        pre(); gdn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(10):
+            pre(); gdn()
+        torch.cuda.synchronize()
+    acc = {}
+    for e in prof.events():
+        if "gdn_chunk" in e.name:
+            nm = e.name.split("(")[0].replace("void ivl::", "")
+            a = acc.setdefault(nm, [0.0, 0])
+            a[0] += float(e.device_time if hasattr(e, "device_time") else e.cuda_time); a[1] += 1
+    print(f"T={T} predecessor={name:10s}: " + "; ".join(f"{k}: {v[0] / v[1]:.1f} us x{v[1]}" for k, v in acc.items()), flush=True)

@@ -45,7 +45,7 @@ for it in range(3):
     t = trace.cpu().tolist()
     n = max(t[40], 1)
     if t[42] == 2:  # round-5 prefill kernel (8 compute waves, no loaders): wave 0 = key half 0, wave 4 = key half 1 (rotated)
-        print(f"--- iter {it} (prefill8 kernel): tiles {t[40]} | prologue {t[32]} | tile loop {t[47]} = {t[47]//n} per tile | epilogue {t[38]} | total {t[39]}")
+        print(f"--- iter {it} (prefill kernel, round 5): tiles {t[40]} | prologue {t[32]} | tile loop {t[47]} = {t[47]//n} per tile | epilogue {t[38]} | total {t[39]}")
         print(f"      key half 0 per tile: QK + row max {t[33]//n} | stage tile t+2 {t[34]//n} | exps + PV {t[35]//n} | vmcnt + barrier {t[36]//n}")
         print(f"      key half 1 per tile: row max {t[50]//n} | stage tile t+2 {t[51]//n} | exps + PV + QK(t+1) {t[52]//n} | vmcnt + barrier {t[53]//n}")
         continue
