@@ -2197,12 +2197,13 @@ static void gdn_chunk_init_device() {
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 1>, attr, lds16);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<false, 2>, attr, lds16);
     const int lds8 = scan_lds_bytes(2, true) > P_BYTES ? scan_lds_bytes(2, true) : P_BYTES;
+    const int lds8_long = lds8 > 2 * P_BODY_STRIDE ? lds8 : 2 * P_BODY_STRIDE;      // the long-call form runs TWO pre-pass bodies per workgroup
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 0>, attr, lds8);
     (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 1>, attr, lds8);
-    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 2>, attr, lds8);
+    (void)hipFuncSetAttribute((const void*)gdn_chunk_single_kernel<true, 2>, attr, lds8_long);
     auto min3 = [](int a, int b, int c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
     g_resident[dev][0] = min3(single_occupancy<false, 0>(lds16, cus), single_occupancy<false, 1>(lds16, cus), single_occupancy<false, 2>(lds16, cus));
-    g_resident[dev][1] = min3(single_occupancy<true, 0>(lds8, cus), single_occupancy<true, 1>(lds8, cus), single_occupancy<true, 2>(lds8, cus));
+    g_resident[dev][1] = min3(single_occupancy<true, 0>(lds8, cus), single_occupancy<true, 1>(lds8, cus), single_occupancy<true, 2>(lds8_long, cus));
     // the status slots: 512 bytes of pinned, device-mapped host memory for the life of the process (the one thing the library
     // allocates; without it a failed wait is still recorded in the sync area and found by ivl_gdn_sync_status)
     void* hp = nullptr;
@@ -2322,7 +2323,10 @@ static int gdn_chunk_launch(const void* q, const void* k, const void* v, const f
       sy.nsplit = nseg < NSTART ? nseg : NSTART;                   // starter chunks: at least what the scan's loaders request before the first chunk step
       int nprep = resident - 8 * BH;                               // persistent pre-pass workgroups: what the chip holds beside the scan
       if (nprep > (nseg - sy.nsplit) * BH / 2) nprep = (nseg - sy.nsplit) * BH / 2;   // (two chunk-head pairs per workgroup and round)
-      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(2 * sy.nsplit * BH + nprep + 8 * BH), dim3(LONG_THREADS), lds1, st, *pf, wsb,
+      // two pre-pass bodies per workgroup: 2 x 70 KB whatever the scan's own LDS need is (the fp8 scan images are half the bf16 ones:
+      // until round 5 an fp8 long call ran its second body outside the launch's LDS allocation)
+      const int lds2 = lds1 > 2 * P_BODY_STRIDE ? lds1 : 2 * P_BODY_STRIDE;
+      hipLaunchKernelGGL((gdn_chunk_single_kernel<F8, 2>), dim3(2 * sy.nsplit * BH + nprep + 8 * BH), dim3(LONG_THREADS), lds2, st, *pf, wsb,
                          (bf16_t*)o, sv, hin, hin_dt, hout, hout_dt, T, H, BH, c0 * GC, nseg, nprep, scale, sy);
       int rc = check_launch("ivl_gdn_chunk_fused_fwd(overlapped launch)");
       if (rc != IVL_OK) return rc;

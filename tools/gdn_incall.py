@@ -6,15 +6,17 @@ inside a configs[3] call (100 us)?  (VERDICT r4 #4.)  The launch is timed (profi
   rewritten  : the projection buffer (101 MB) rewritten by a copy kernel in front (what the in-projection GEMM does: the 101 MB
                are dirty in the writing XCDs' L2s at the kernel boundary and come back from the memory side)
   gemm       : the projection written by the real [4096 x 2048] x [2048 x 12320] library GEMM in front
-usage: gdn_incall.py [T=4096]"""
+usage: gdn_incall.py [T=4096] [libpath]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from torch.profiler import ProfilerActivity, profile
-from infinitevl_amd import ops
+from infinitevl_amd import _lib, ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+if len(sys.argv) > 2:
+    _lib.load(sys.argv[2])
 dev = torch.device("cuda", 0)
 B, H, K, V = 1, 16, 128, 256
 Dq, Dk, Dv = H * K, H * K, H * V

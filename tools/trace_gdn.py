@@ -31,6 +31,10 @@ if os.environ.get("IVL_TRACE_FUSED"):          # the pre-pass with the conv / ga
     cs = [rn(B, D_, 4) for D_ in (Dq, Dk, Dv)]
     A32, dt32 = torch.randn(H, device=dev, generator=g_), torch.randn(H, device=dev, generator=g_)
     run = lambda: ops.gdn_chunk_fused(proj, cols, cw, cs, cs, A32, dt32, H, K, V, initial_state=state, final_state_out=state)
+if os.environ.get("IVL_TRACE_COLD"):           # every traced launch behind a 1 GiB read sweep: its inputs come from HBM (as inside a real call)
+    big_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    run_hot = run
+    run = lambda: (big_.sum(), run_hot())[1]
 for it in range(5):
     run()
 torch.cuda.synchronize()
