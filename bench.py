@@ -312,6 +312,17 @@ def kernel_timings(device, chunk, window, only=None, live_prefill=None, live_dec
     add("gdn_decode_step(decode: convs+gates+rule+norm, 1 launch)", lambda i: ops.gdn_decode_step(
         proj1, cols6, cw, css[i % NS], A32, dt32, wn, 1e-5, states[i % NS], H, K, V, K ** -0.5), 96, "decode", 27, "hbm",
         2.0 * ld + sbytes + 2.0 * H * V)
+    # the measured alternative (round 5, off by default: ops._SPLIT_DECODE): the step on 64 workgroups + the gated norm and the q / k
+    # conv-state shift in the o_proj launch -- 1.953 vs 1.925 ms per token against the one-launch step + plain o_proj
+    wo_ = rn(2048, H * V)
+    add("gdn_decode_split(64 workgroups, un-normalised output)", lambda i: ops.gdn_decode_split(
+        proj1, (cols6[0], cols6[1], cols6[2], cols6[4], cols6[5]), cw, css[i % NS], A32, dt32, states[i % NS], H, K, V, K ** -0.5),
+        96, "other", 0, "hbm", 2.0 * ld + sbytes + 2.0 * H * V)
+    oraw_ = rn(B, 1, H * V)
+    add("decode linear gated norm + gdn o_proj [2048x4096] (+ q/k conv-state shift)", lambda i: ops.gdn_out_linear(
+        oraw_, proj1, cols6[3], cols6[0], cols6[1], wn, 1e-5, css[i % NS][0], css[i % NS][1], wo_, None, H), 96, "other", 0, "hbm",
+        2.0 * 2048 * H * V + 2.0 * (2048 + 2 * H * V))
+    del wo_
     qd, kd1, vd1 = qkv_views(1)
     add("swa_decode", lambda i: ops.swa_forward(qd, kd1, vd1, window=window, scaling=d ** -0.5, k_cache=rings[i % NSW][0],
                                                 v_cache=rings[i % NSW][1], pos_dev=pos_dev, append=True), 96, "decode", 9, "hbm",

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 9
+#define IVL_ABI_VERSION 10
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -335,6 +335,26 @@ IVL_API int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, int
                             void* conv_state_q, void* conv_state_k, void* conv_state_v, const float* A_log,
                             const float* dt_bias, const void* norm_weight, float eps, void* state, int state_dtype,
                             void* y, int B, int H, int K, int V, float scale, void* stream);
+
+/* The same step on 4 x as many workgroups (round 5): a workgroup = (sequence, head, quarter of the 256 value columns); the delta
+ * rule is column-local, so the quarters exchange nothing.  What spans a head moves into the NEXT launch
+ * (ivl_gdn_out_linear_small_m_fwd, the o_proj weight stream): the gated RMSNorm, and the shift of the q / k conv states (every
+ * quarter reads them).  Here: conv states of q and k are READ ONLY, the v conv state and the recurrent state are updated in
+ * place, o_raw [B, H*256] bf16 receives the delta rule's UN-NORMALISED output (the bf16 rounding point of the recurrent kernel).
+ * ivl_gdn_decode_split_fwd + ivl_gdn_out_linear_small_m_fwd == ivl_gdn_decode_step_fwd + ivl_linear_small_m_fwd, bit for bit
+ * (outputs, recurrent state, all three conv states).  Replaces std:1241-1342 at q_len == 1. */
+IVL_API int ivl_gdn_decode_split_fwd(const void* proj, int64_t ld, int col_q, int col_k, int col_v, int col_a, int col_b,
+                             const void* conv_wq, const void* conv_wk, const void* conv_wv, const void* conv_state_q,
+                             const void* conv_state_k, void* conv_state_v, const float* A_log, const float* dt_bias,
+                             void* state, int state_dtype, void* o_raw, int B, int H, int K, int V, float scale, void* stream);
+/* y[M,N] = bf16(o_norm(o_raw, gate)[M, H*256] W[N, H*256]^T + bias): the GDN output projection of a decode step (std:1336-1342)
+ * with FusedRMSNormGated (fla:modules/fused_norm_gate.py:778-796; 256-wide heads, eps) in the prologue of the weight stream.
+ * gate = first gate element of row 0 of the fused projection (row stride gate_ld elements); norm_weight bf16 [256].  Also shifts
+ * the conv states [M, H*128, 4] of q and k by the step's raw projection values (proj + col_q / col_k, row stride proj_ld): the
+ * second half of ivl_gdn_decode_split_fwd's state update.  M <= 4, H <= 16. */
+IVL_API int ivl_gdn_out_linear_small_m_fwd(const void* o_raw, const void* gate, int64_t gate_ld, const void* norm_weight, float eps,
+                                   int H, const void* proj, int64_t proj_ld, int col_q, int col_k, void* conv_state_q,
+                                   void* conv_state_k, const void* w, const void* bias, void* y, int M, int N, int K, void* stream);
 
 /* nn.Linear for the single-token decode step (M <= 4 rows): y[M,N] = bf16(x[M,K] W[N,K]^T + bias[N]).
  * Replaces the q/k/v/o, GDN in/out, MLP and tied lm_head projections (std:1047-1054, 1215-1240, 945, 2091-2092)

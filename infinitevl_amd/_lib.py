@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd", "ivl_norm_linear_small_m_fwd",
     "ivl_gdn_sync_status", "ivl_gdn_sync_reset", "ivl_gdn_resident_blocks",
     "ivl_short_conv_bias_fwd", "ivl_rmsnorm_swish_gate_res_fwd", "ivl_gdn_recurrent_f16_fwd",
+    "ivl_gdn_decode_split_fwd", "ivl_gdn_out_linear_small_m_fwd",
 )
 
 
@@ -136,6 +137,10 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_decode_step_fwd.restype = i
     lib.ivl_gdn_decode_step_fwd.argtypes = [vp, i64, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, i,
                                             vp, i, i, i, i, f, vp]
+    lib.ivl_gdn_decode_split_fwd.restype = i
+    lib.ivl_gdn_decode_split_fwd.argtypes = [vp, i64, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, f, vp]
+    lib.ivl_gdn_out_linear_small_m_fwd.restype = i
+    lib.ivl_gdn_out_linear_small_m_fwd.argtypes = [vp, vp, i64, vp, f, i, vp, i64, i, i, vp, vp, vp, vp, vp, i, i, i, vp]
     lib.ivl_linear_swiglu_small_m_fwd.restype = i
     lib.ivl_linear_swiglu_small_m_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ivl_norm_linear_small_m_fwd.restype = i

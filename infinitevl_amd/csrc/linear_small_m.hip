@@ -219,6 +219,101 @@ static int lsm_dispatch(const void* x, const void* w, const void* bias, void* y,
   return check_launch(who);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// GDN output projection of a decode step with the GATED RMSNorm in its prologue (round 5): x = o_norm(o, gate) is
+// formed by every workgroup itself -- per head a 256-wide statistic of the un-normalised bf16 delta-rule output (8 KB per row,
+// L2-resident) and the gate columns of the projection row -- with the arithmetic of gdn_decode_step_kernel's last block (lane l of
+// a wave holds elements 4l .. 4l + 3 of a head: same sums, same roundings: bit-identical), staged in LDS, then the o_proj weight
+// stream reads x from there.  What makes it worth a kernel: the decode step itself can then run on 4 x as many workgroups
+// (gdn_decode_split_kernel) because nothing spans a head any more.  The first workgroups also shift the conv states of q and k
+// (new state = taps 1..3 + the step's raw projection value): every quarter workgroup of the split step READS those states, so
+// they can only be written by the NEXT launch.
+struct GdnOutArgs {
+  const bf16_t* gate; long long gate_ld;           // gate[m][h * 256 + c] = gate[m * gate_ld + h * 256 + c]
+  const bf16_t* norm_w; float eps; int H;
+  const bf16_t* proj; long long proj_ld; int col_q, col_k;
+  bf16_t* cq; bf16_t* ck; int Dq;                  // conv states [M, Dq, 4] of q and k
+};
+template <int M>
+__global__ __launch_bounds__(256) void linear_gdn_out_kernel(const bf16_t* __restrict__ o_raw, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N, int K, GdnOutArgs ga) {
+  __shared__ __attribute__((aligned(16))) u32x4 s_x[M * (LSM_NORM_KMAX / 8)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  const int nchunk = K >> 3;
+  const int row = min((int)blockIdx.x * 4 + wave, N - 1);
+  const u32x4* wrow = (const u32x4*)(w + (size_t)row * K);
+  // ---- conv-state shift of q and k (a few items per workgroup; independent of everything else here) ----
+  {
+    const int total = M * 2 * ga.Dq;
+    for (int item = (int)blockIdx.x * 256 + tid; item < total; item += (int)gridDim.x * 256) {
+      const int ch = item % ga.Dq, rest = item / ga.Dq, isk = rest & 1, m = rest >> 1;
+      bf16_t* st = (isk ? ga.ck : ga.cq) + ((size_t)m * ga.Dq + ch) * 4;
+      const u32x2 sv = *(const u32x2*)st;
+      const bf16_t xr = ga.proj[(size_t)m * ga.proj_ld + (isk ? ga.col_k : ga.col_q) + ch];
+      *(u32x2*)st = u32x2{(sv.x >> 16) | (sv.y << 16), (sv.y >> 16) | ((unsigned int)xr << 16)};
+    }
+  }
+  // ---- the rows' pieces first (o, gate, norm weight: 4 heads per wave), then the first weight batch, then the norm ----
+  constexpr int HPW = 4;                           // heads per wave: head = wave + 4 i (H <= 16)
+  u32x2 oraw[M][HPW], graw[M][HPW];
+  const u32x2 wv = *(const u32x2*)(ga.norm_w + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < HPW; ++i) {
+    const int hh = min(wave + 4 * i, ga.H - 1);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      oraw[m][i] = *(const u32x2*)(o_raw + (size_t)m * K + hh * 256 + 4 * lane);
+      graw[m][i] = *(const u32x2*)(ga.gate + (size_t)m * ga.gate_ld + hh * 256 + 4 * lane);
+    }
+  }
+  float acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = 0.f;
+  bool first = true;
+  for (int c0 = lane; c0 < nchunk; c0 += 64 * LSM_U) {
+    u32x4 wvv[LSM_U];
+#pragma unroll
+    for (int u = 0; u < LSM_U; ++u) wvv[u] = __builtin_nontemporal_load(wrow + min(c0 + 64 * u, nchunk - 1));
+    if (first) {                                   // (workgroup-uniform trip count)
+      const float wf[4] = {bflo(wv.x), bfhi(wv.x), bflo(wv.y), bfhi(wv.y)};
+#pragma unroll
+      for (int i = 0; i < HPW; ++i) {
+        const int hh = wave + 4 * i;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const float o4[4] = {bflo(oraw[m][i].x), bfhi(oraw[m][i].x), bflo(oraw[m][i].y), bfhi(oraw[m][i].y)};
+          const float gf[4] = {bflo(graw[m][i].x), bfhi(graw[m][i].x), bflo(graw[m][i].y), bfhi(graw[m][i].y)};
+          const float ss = wave_sum(o4[0] * o4[0] + o4[1] * o4[1] + o4[2] * o4[2] + o4[3] * o4[3]);
+          const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + ga.eps);
+          float y4[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) y4[c] = o4[c] * rstd * wf[c] * gf[c] * sigmoidf_(gf[c]);
+          if (hh < ga.H)
+            *(u32x2*)((bf16_t*)s_x + (size_t)m * LSM_NORM_KMAX + hh * 256 + 4 * lane) = u32x2{pack2bf(y4[0], y4[1]), pack2bf(y4[2], y4[3])};
+        }
+      }
+      __syncthreads();
+      first = false;
+    }
+#pragma unroll
+    for (int u = 0; u < LSM_U; ++u) {
+      const int c = c0 + 64 * u;
+      const int cc = min(c, nchunk - 1);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const u32x4 xl = c < nchunk ? s_x[m * (LSM_NORM_KMAX / 8) + cc] : u32x4{0u, 0u, 0u, 0u};
+        acc[m] = dot8(wvv[u], xl, acc[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float sum = wave_sum(acc[m]);
+    if (lane == 0 && (int)blockIdx.x * 4 + wave < N)
+      y[(size_t)m * N + row] = f2bf(sum + (bias != nullptr ? bf2f(bias[row]) : 0.f));
+  }
+}
+
 }  // namespace ivl
 
 using namespace ivl;
@@ -243,4 +338,35 @@ extern "C" int ivl_norm_linear_small_m_fwd(const void* x, const void* residual, 
   NormArgs na;
   na.residual = (const bf16_t*)residual; na.weight = (const bf16_t*)norm_weight; na.h_out = (bf16_t*)h_out; na.eps = eps;
   return lsm_dispatch<true>(x, w, bias, y, M, N, K, glu != 0, na, stream, "ivl_norm_linear_small_m_fwd");
+}
+
+// o_proj of a GDN decode step with the gated RMSNorm in the prologue and the q / k conv-state shift riding along (see
+// linear_gdn_out_kernel; pairs with ivl_gdn_decode_split_fwd).  o_raw bf16 [M, H*256] (un-normalised delta-rule output), gate =
+// first gate element of row 0 (row stride gate_ld elements), proj = the step's projection rows (row stride proj_ld), conv states
+// [M, Dq, 4] of q and k (updated in place).  y[M, N] = o_norm(o_raw, gate) W^T (+ bias).
+extern "C" int ivl_gdn_out_linear_small_m_fwd(const void* o_raw, const void* gate, int64_t gate_ld, const void* norm_weight, float eps,
+                                              int H, const void* proj, int64_t proj_ld, int col_q, int col_k, void* conv_state_q,
+                                              void* conv_state_k, const void* w, const void* bias, void* y, int M, int N, int K,
+                                              void* stream) {
+  IVL_REQUIRE(o_raw && gate && norm_weight && proj && conv_state_q && conv_state_k && w && y, IVL_ERR_INVALID_ARG,
+              "ivl_gdn_out_linear_small_m_fwd: NULL pointer");
+  IVL_REQUIRE(M >= 1 && M <= 4, IVL_ERR_UNSUPPORTED, "ivl_gdn_out_linear_small_m_fwd: M=%d (built for 1..4 rows)", M);
+  IVL_REQUIRE(H >= 1 && H <= 16 && K == H * 256 && K <= LSM_NORM_KMAX && N > 0, IVL_ERR_UNSUPPORTED,
+              "ivl_gdn_out_linear_small_m_fwd: H=%d K=%d N=%d (K = H * 256 <= %d)", H, K, N, LSM_NORM_KMAX);
+  IVL_REQUIRE(gate_ld % 4 == 0 && ((size_t)gate & 7) == 0 && ((size_t)o_raw & 7) == 0, IVL_ERR_INVALID_ARG,
+              "ivl_gdn_out_linear_small_m_fwd: o_raw / gate rows must be 8-byte aligned");
+  GdnOutArgs ga;
+  ga.gate = (const bf16_t*)gate; ga.gate_ld = gate_ld; ga.norm_w = (const bf16_t*)norm_weight; ga.eps = eps; ga.H = H;
+  ga.proj = (const bf16_t*)proj; ga.proj_ld = proj_ld; ga.col_q = col_q; ga.col_k = col_k;
+  ga.cq = (bf16_t*)conv_state_q; ga.ck = (bf16_t*)conv_state_k; ga.Dq = H * 128;
+  const dim3 grid((N + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t *op = (const bf16_t*)o_raw, *wp = (const bf16_t*)w, *bp = (const bf16_t*)bias;
+  switch (M) {
+    case 1: hipLaunchKernelGGL((linear_gdn_out_kernel<1>), grid, dim3(256), 0, st, op, wp, bp, (bf16_t*)y, N, K, ga); break;
+    case 2: hipLaunchKernelGGL((linear_gdn_out_kernel<2>), grid, dim3(256), 0, st, op, wp, bp, (bf16_t*)y, N, K, ga); break;
+    case 3: hipLaunchKernelGGL((linear_gdn_out_kernel<3>), grid, dim3(256), 0, st, op, wp, bp, (bf16_t*)y, N, K, ga); break;
+    default: hipLaunchKernelGGL((linear_gdn_out_kernel<4>), grid, dim3(256), 0, st, op, wp, bp, (bf16_t*)y, N, K, ga); break;
+  }
+  return check_launch("ivl_gdn_out_linear_small_m_fwd");
 }

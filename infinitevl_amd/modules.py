@@ -271,6 +271,19 @@ class GatedDeltaNet(nn.Module):
         w = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
         if (T == 1 and layer is not None and prev[0] is not None and h0 is not None and Dk == Dq
                 and h0.data_ptr() == layer.recurrent_state.data_ptr() and K == 128 and V == 256):
+            ow, ob = self.o_proj.weight, self.o_proj.bias
+            if (ops._SPLIT_DECODE and B <= 4 and H <= 16 and ow.dtype == torch.bfloat16 and ow.is_contiguous() and cg % 4 == 0
+                    and ld % 4 == 0 and (ob is None or (ob.dtype == torch.bfloat16 and ob.is_contiguous()))):
+                # decode step on 64 workgroups (sequence x head x column quarter); the gated norm and the q / k conv-state shift ride
+                # in the o_proj launch: the same two launches, 4 x the memory parallelism for the 2 MB of state (bit-identical)
+                o_raw = ops.gdn_decode_split(proj, (cq, ck, cv, ca, cb),
+                                             (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight), outs, A32, dt32,
+                                             layer.recurrent_state, H, K, V, K ** -0.5)
+                y = ops.gdn_out_linear(o_raw, proj, cg, cq, ck, w, self.norm_eps, outs[0], outs[1], ow, ob, H)
+                past_key_values.update(layer_idx=self.layer_idx, key_states=None, value_states=None, conv_state=outs,
+                                       recurrent_state=layer.recurrent_state,
+                                       cache_kwargs={"op": "set", "delta_len": T, "cache_position": cache_position})
+                return y, None
             # decode step: convs + gates + delta rule + gated norm in ONE launch, cache tensors updated in place
             o = ops.gdn_decode_step(proj, (cq, ck, cv, cg, ca, cb),
                                     (self.q_conv1d.weight, self.k_conv1d.weight, self.v_conv1d.weight), outs, A32, dt32,

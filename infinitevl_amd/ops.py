@@ -746,6 +746,49 @@ def gdn_decode_step(proj: torch.Tensor, cols, conv_weights, conv_states, A_log32
     return y
 
 
+# The GDN decode step on 64 workgroups + gated norm / conv-state shift in the o_proj launch (gdn_decode_split + gdn_out_linear):
+# bit-identical to the one-launch step + plain o_proj, built and measured in round 5 -- 1.953 vs 1.925 ms per token
+# at 8K context (tools/ab_decode_split.py, ABAB in one process): it LOSES, so the modules keep the one-launch step.
+_SPLIT_DECODE = False
+
+
+def gdn_decode_split(proj: torch.Tensor, cols, conv_weights, conv_states, A_log32, dt_bias32, state: torch.Tensor,
+                     H: int, K: int, V: int, scale: float) -> torch.Tensor:
+    """The GDN decode step on 4 x as many workgroups (one per sequence, head and quarter of the value columns): returns the delta
+    rule's UN-NORMALISED bf16 output [B,1,H*V]; the v conv state and the recurrent state are updated in place, the q / k conv
+    states are only read -- gdn_out_linear (the o_proj launch) applies the gated norm and shifts them.  cols = (col_q, col_k,
+    col_v, col_a, col_b)."""
+    _need_gpu(proj, state)
+    B, T, ld = proj.shape
+    assert T == 1 and proj.is_contiguous() and proj.dtype == torch.bfloat16 and state.is_contiguous()
+    o_raw = torch.empty(B, 1, H * V, dtype=torch.bfloat16, device=proj.device)
+    wq, wk, wv = conv_weights
+    sq, sk, sv = conv_states
+    _lib.check(_lib.load().ivl_gdn_decode_split_fwd(
+        _p(proj), ld, cols[0], cols[1], cols[2], cols[3], cols[4], _p(wq), _p(wk), _p(wv), _p(sq), _p(sk), _p(sv),
+        _p(A_log32), _p(dt_bias32), _p(state), _DT_CODE[state.dtype], _p(o_raw), B, H, K, V, float(scale), _stream(proj)))
+    return o_raw
+
+
+def gdn_out_linear(o_raw: torch.Tensor, proj: torch.Tensor, col_g: int, col_q: int, col_k: int, norm_weight: torch.Tensor, eps: float,
+                   conv_state_q: torch.Tensor, conv_state_k: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                   H: int) -> torch.Tensor:
+    """o_proj(o_norm(o_raw, gate)) for a decode step, one launch: the gated RMSNorm runs in the prologue of the weight stream, and
+    the launch shifts the q / k conv states (the second half of gdn_decode_split's state update).  proj [B,1,ld] is the step's
+    fused projection (gate columns at col_g, raw q / k columns at col_q / col_k)."""
+    _need_gpu(o_raw, proj, weight)
+    B, T, ld = proj.shape
+    K = o_raw.shape[-1]
+    N = weight.shape[0]
+    assert T == 1 and o_raw.is_contiguous() and weight.is_contiguous() and weight.dtype == torch.bfloat16
+    y = torch.empty(B, 1, N, dtype=torch.bfloat16, device=o_raw.device)
+    gate = proj.view(B, ld)[:, col_g:]
+    _lib.check(_lib.load().ivl_gdn_out_linear_small_m_fwd(
+        _p(o_raw), ctypes.c_void_p(gate.data_ptr()), ld, _p(norm_weight), float(eps), H, _p(proj), ld, col_q, col_k,
+        _p(conv_state_q), _p(conv_state_k), _p(weight), _p(bias) if bias is not None else None, _p(y), B, N, K, _stream(o_raw)))
+    return y
+
+
 def rmsnorm_swish_gate_strided(x: torch.Tensor, gate_base: torch.Tensor, gate_ld: int, weight: torch.Tensor,
                                eps: float) -> torch.Tensor:
     """Gated RMSNorm with the gate read in place from a fused projection buffer.  x [B,T,H,256] bf16

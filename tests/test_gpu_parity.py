@@ -2499,3 +2499,68 @@ def test_swa_prefill_is_bit_stable_under_a_co_running_stream():
         torch.cuda.synchronize()
         for (o, kc2, vc2), (_, (ro, rk, rv)) in zip(outs, cases):
             assert torch.equal(o, ro) and torch.equal(kc2, rk) and torch.equal(vc2, rv), it
+
+
+@pytest.mark.parametrize("B,H,state_dtype", [(1, 16, torch.bfloat16), (2, 16, torch.float32), (4, 16, torch.bfloat16), (3, 5, torch.bfloat16)])
+def test_gdn_decode_split_plus_out_linear_equals_one_launch_step_plus_linear(B, H, state_dtype):
+    """Round 5: the decode step on 64 workgroups (sequence x head x quarter of the value columns,
+    ivl_gdn_decode_split_fwd) with the gated RMSNorm and the q / k conv-state shift in the prologue of the o_proj weight stream
+    (ivl_gdn_out_linear_small_m_fwd) equals ivl_gdn_decode_step_fwd + ivl_linear_small_m_fwd BIT FOR BIT over several steps: the
+    projected output, the recurrent state and all three conv states (same 16-row fma chains and group order in the column sums,
+    the norm on the same lane -> element map)."""
+    from infinitevl_amd import ops
+    K, V = 128, 256
+    Dq, Dv = H * K, H * V
+    cols = (0, Dq, 2 * Dq, 2 * Dq + Dv, 2 * Dq + 2 * Dv, 2 * Dq + 2 * Dv + H)      # q, k, v, g, a, b
+    ld = cols[5] + H
+    ld += (-ld) % 8
+    g_ = torch.Generator(device=DEV).manual_seed(B * 100 + H)
+    rn = lambda *sh: bf(torch.randn(*sh, device=DEV, generator=g_))      # noqa: E731
+    state0 = rn(B, H, K, V).to(state_dtype)
+    conv0 = [rn(B, D, 4) for D in (Dq, Dq, Dv)]
+    cw = [rn(D, 1, 4) * 0.5 for D in (Dq, Dq, Dv)]
+    A32, dt32 = torch.randn(H, device=DEV, generator=g_), torch.randn(H, device=DEV, generator=g_)
+    wn = rn(V)
+    N = 2048
+    wo, bo = rn(N, Dv) * 0.05, (rn(N) if H == 5 else None)
+    st_a, st_b = state0.clone(), state0.clone()
+    ca, cb = [c.clone() for c in conv0], [c.clone() for c in conv0]
+    for step in range(4):
+        proj = rn(B, 1, ld)
+        y1 = ops.gdn_decode_step(proj, cols, cw, ca, A32, dt32, wn, 1e-5, st_a, H, K, V, K ** -0.5)
+        o1 = ops.linear(y1, wo, bo)
+        o_raw = ops.gdn_decode_split(proj, (cols[0], cols[1], cols[2], cols[4], cols[5]), cw, cb, A32, dt32, st_b, H, K, V, K ** -0.5)
+        o2 = ops.gdn_out_linear(o_raw, proj, cols[3], cols[0], cols[1], wn, 1e-5, cb[0], cb[1], wo, bo, H)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2), step
+        assert torch.equal(st_a, st_b), step
+        for x_a, x_b in zip(ca, cb):
+            assert torch.equal(x_a, x_b), step
+    assert torch.isfinite(o2.float()).all() and not torch.equal(st_a, state0)
+
+
+def test_decode_tokens_with_the_split_step_equal_the_one_launch_step():
+    """Module level: greedy decode through the 4-layer stack with ops._SPLIT_DECODE on / off: tokens, logits and caches bit-equal."""
+    from infinitevl_amd import ops
+    from infinitevl_amd.harness import greedy_decode
+    stack, hc, _, _ = _small_stack(window=96)
+    x = bf(torch.randn(1, 70, hc.hidden_size, device=DEV) * 0.5)
+    res = []
+    for flag in (True, False):
+        ops._SPLIT_DECODE = flag
+        try:
+            with torch.no_grad():
+                cache = stack.allocate_inference_cache(1)
+                _, lg = stack(inputs_embeds=x, past_key_values=cache)
+                toks = greedy_decode(stack, cache, lg[:, -1].argmax(-1), steps=12)
+                _, lg2 = stack(input_ids=toks[:, -1:], past_key_values=cache)
+            res.append((toks, lg2, cache))
+        finally:
+            ops._SPLIT_DECODE = False
+    (t1, l1, c1), (t2, l2, c2) = res
+    assert torch.equal(t1, t2) and torch.equal(l1, l2)
+    for a, b_ in zip(c1.layers, c2.layers):
+        if not getattr(a, "is_sliding", False):
+            assert torch.equal(a.recurrent_state, b_.recurrent_state)
+            for nm in ("conv_state_q", "conv_state_k", "conv_state_v"):
+                assert torch.equal(getattr(a, nm), getattr(b_, nm)), nm
