@@ -817,6 +817,216 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// MODE 11 / 12 (attn8p_proto<ACC2>): mode 8's data path (real K / V streams, 4 stages, no loader waves) with the compute of the full
+// 256-VGPR design: a register block each for the K and the V^T fragments, every product's fragments requested ONE PHASE AHEAD
+// (K(t + 1) before the PV(t) MFMAs, V(t) right behind the QK^T(t) MFMAs), every wave's 4 DMA pieces behind MFMAs 1, 3, 5, 7 of its PV
+// product; ACC2: QK^T on two accumulators (two dependent chains of four).
+template <int ACC2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn8p_proto(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                                              const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int ntiles, float sc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
+  const int rg = wave & 3, kh = wave >> 2;
+  const int row0 = blockIdx.x * 128 + rg * 32;
+  const unsigned int lds_base = (unsigned int)(size_t)smem;
+  const int r_in = lane >> 4, pp = lane & 15;
+  const unsigned int k_src = (unsigned int)(r_in * 256 + ((pp ^ (4 * (wave & 3) + r_in)) << 4));
+  const unsigned int v_src = (unsigned int)(r_in * 256 + (((((pp >> 2) ^ r_in) << 2) | (pp & 3)) << 4));
+  const int kvh = ((int)blockIdx.x & 7) >> 2;
+  const size_t head_bytes = (size_t)ntiles * 64 * 256;
+  auto dma_piece = [&](int tile, int st, int i) __attribute__((always_inline)) {
+    const int isv = i & 1, j = i >> 1;
+    const int c = (wave & 3) + 4 * (2 * (wave >> 2) + j);
+    const unsigned char* base = (const unsigned char*)(isv ? v : k) + kvh * head_bytes + (size_t)tile * 16384 + (size_t)c * 1024;
+    const unsigned int dst = lds_base + (unsigned int)st * STAGE4 + (isv ? 16384u : 0u) + 1024u * c;
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(isv ? v_src : k_src), "s"(dst), "s"(base) : "memory");
+  };
+  u32x4 qf[8];
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(q + (size_t)(row0 + l31) * D + 16 * kd + 8 * hi5);
+#pragma unroll
+  for (int kd = 0; kd < 8; ++kd) asm volatile("" : "+v"(qf[kd]));
+  f32x16 oacc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int t0 = 0; t0 < 3; ++t0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(t0, t0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned int k_base = (unsigned int)((32 * kh + l31) * 256 + ((l15 >> 1) << 5) + ((hi5 ^ (l15 & 1)) << 4));
+  const unsigned int v_base = (unsigned int)(16384 + (32 * kh + 4 * hi5 + (l15 >> 2)) * 256 + ((l15 >> 2) << 6) + 32 * ((lane >> 4) & 1) + 8 * (l15 & 3));
+  u32x4 fr[8], fv[8];
+  auto load_k = [&](int st) __attribute__((always_inline)) {
+    const unsigned int kb = k_base + (unsigned int)st * STAGE4;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) fr[kd] = *(const u32x4*)(smem + (kb ^ (unsigned int)(kd << 5)));
+  };
+  auto load_v = [&](int st) __attribute__((always_inline)) {
+    const unsigned int vb = v_base + (unsigned int)st * STAGE4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const unsigned char* vp = smem + (vb ^ (unsigned int)(mt << 6)) + 16 * ks * 256;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vp);
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 8 * 256));
+        u32x2 w0, w1;
+        __builtin_memcpy(&w0, &a0, 8);
+        __builtin_memcpy(&w1, &a1, 8);
+        fv[4 * ks + mt] = u32x4{w0.x, w0.y, w1.x, w1.y};
+      }
+  };
+  auto qk_mfma = [&](f32x16& s) __attribute__((always_inline)) {
+    if constexpr (ACC2 != 0) {
+      f32x16 s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int kd = 0; kd < 8; kd += 2) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd]), mf(qf[kd]), s, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd + 1]), mf(qf[kd + 1]), s1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += s1[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fr[kd]), mf(qf[kd]), s, 0, 0, 0);
+    }
+  };
+  auto smax = [&](f32x16& s) __attribute__((always_inline)) {
+    float rmax = vmax2(__builtin_fmaxf(s[0], s[1]), s[2]);
+    rmax = vmax2(rmax, s[3]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) rmax = vmax3(rmax, s[r], s[r + 1]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+    rmax = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sc;
+    const float m_new = vmax2(m_run, rmax);
+    if (__any(m_new > m_run + 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) oacc[mt] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+  };
+  auto sexp = [&](f32x16& s, u32x4 (&pf)[2]) __attribute__((always_inline)) {
+    const float mu = m_run;
+    float rsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sc, -mu));
+      s[r] = p;
+      rsum += p;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      pf[ks] = u32x4{pack2bf(s[8 * ks + 0], s[8 * ks + 1]), pack2bf(s[8 * ks + 2], s[8 * ks + 3]),
+                     pack2bf(s[8 * ks + 4], s[8 * ks + 5]), pack2bf(s[8 * ks + 6], s[8 * ks + 7])};
+    l_run += rsum;
+  };
+  auto pv_mfma = [&](const u32x4 (&pf)[2], int tile3, int st3, bool more) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf(fv[4 * ks + mt]), mf(pf[ks]), oacc[mt], 0, 0, 0);
+        const int i = 4 * ks + mt;
+        if (more && (i & 1)) dma_piece(tile3, st3, i >> 1);
+      }
+  };
+  auto tile_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x16 sA;
+  u32x4 pA[2];
+  if (kh == 0) {
+    load_k(0);
+#pragma nounroll
+    for (int t = 0; t < ntiles; ++t) {
+      const int st = t & 3, st1 = (t + 1) & 3, st3 = (t + 3) & 3;
+      qk_mfma(sA);
+      load_v(st);
+      smax(sA);
+      sexp(sA, pA);
+      if (t + 1 < ntiles) load_k(st1);
+      pv_mfma(pA, t + 3, st3, t + 3 < ntiles);
+      if (t + 3 >= ntiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_piece(t, st3, i);             // (keeps the vmcnt constant: re-fetch into a dead stage)
+      }
+      tile_barrier();
+    }
+  } else {
+    load_k(0);
+    qk_mfma(sA);
+    load_v(0);
+#pragma nounroll
+    for (int t = 0; t < ntiles; ++t) {
+      const int st1 = (t + 1) & 3, st3 = (t + 3) & 3;
+      smax(sA);
+      sexp(sA, pA);
+      if (t + 1 < ntiles) load_k(st1);
+      pv_mfma(pA, t + 3, st3, t + 3 < ntiles);
+      if (t + 3 >= ntiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_piece(t, st3, i);
+      }
+      if (t + 1 < ntiles) {
+        qk_mfma(sA);
+        load_v(st1);
+      }
+      tile_barrier();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  __syncthreads();
+  float* img = (float*)smem + (size_t)(rg * 32 + l31) * 132 + 4 * hi5;
+  float* ml = (float*)(smem + 128 * 528) + (rg * 32 + l31) * 2;
+  if (kh == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[32 * mt + 8 * qd + e] = oacc[mt][4 * qd + e];
+    if (hi5 == 0) { ml[0] = m_run; ml[1] = l_run; }
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const float m1 = ml[0], l1 = ml[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    const float inv = 1.0f / (l_run * a0 + l1 * a1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (oacc[mt][4 * qd + e] * a0 + img[32 * mt + 8 * qd + e] * a1) * inv;
+        bf16_t* op = o + (size_t)(row0 + l31) * D + 32 * mt + 8 * qd + 4 * hi5;
+        *(u32x2*)op = u32x2{pack2bf(x[0], x[1]), pack2bf(x[2], x[3])};
+      }
+  }
+}
+
 extern "C" int attn8_proto_launch(const void* q, const void* k, const void* v, void* o, int rows, int ntiles, float sc, int mode, void* stream) {
   dim3 grid(rows / 256), block(512);
 #define GO(M) { (void)hipFuncSetAttribute((const void*)attn8_proto<M>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
@@ -825,6 +1035,17 @@ extern "C" int attn8_proto_launch(const void* q, const void* k, const void* v, v
     const int lds = mode == 5 ? 2 * STAGE4 : 3 * STAGE4;
     (void)hipFuncSetAttribute((const void*)attn4_proto<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((attn4_proto<2>), dim3(rows / 128), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+    return (int)hipGetLastError();
+  }
+  if (mode == 11 || mode == 12) {
+    const int lds = 4 * STAGE4;
+    if (mode == 11) {
+      (void)hipFuncSetAttribute((const void*)attn8p_proto<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((attn8p_proto<0>), dim3(rows / 128), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn8p_proto<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((attn8p_proto<1>), dim3(rows / 128), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, ntiles, sc);
+    }
     return (int)hipGetLastError();
   }
   if (mode >= 8 && mode <= 10) {
