@@ -113,6 +113,37 @@ def test_gdn_fp8_vs_oracle(B, T, H, h0, sd, inplace):
     assert r["o_vs_exact"] > 5e-3, ("the fp8 variant should not be as accurate as the bf16 one", r)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVL_GDN_FUZZ", "24"))))
+def test_gdn_random_shapes_vs_oracle(seed):
+    """Randomised differential test of the chunk rule (single-launch step form, persistent long-call form, segment seams,
+    ragged last chunks, batches, bf16 / fp32 carried state, in-place state, bf16 and fp8 operands) against the oracle with the
+    reference's rounding points.  IVL_GDN_FUZZ=N runs N seeds (default 24)."""
+    import random
+    r = random.Random(seed)
+    H = r.choice([1, 2, 3, 16])
+    B = r.choice([1, 1, 2, 3])
+    T = r.choice([r.randint(1, 64), r.randint(65, 300), r.randint(257, 1500)])
+    if H == 16 or B == 3:
+        T = min(T, 420)                                                     # keeps the CPU oracle at seconds
+    sd = r.choice([torch.float32, torch.bfloat16])
+    h0, inplace, fp8 = r.random() < 0.7, r.random() < 0.5, r.random() < 0.3
+    res = parity.gdn_op_parity(DEV, "chunk", B, T, H, seed=7000 + seed, with_h0=h0, state_dtype=sd, inplace_state=inplace,
+                               mma_dtype="fp8_e4m3" if fp8 else None)
+    case = dict(B=B, T=T, H=H, h0=h0, sd=str(sd), inplace=inplace, fp8=fp8)
+    assert res["finite"] == 1.0, (res, case)
+    if fp8:
+        assert res["o_vs_fp8model"] < 1e-3 and res["s_vs_fp8model"] < (3e-3 if sd == torch.bfloat16 else 1e-3), (res, case)
+        assert res["o_vs_exact"] < 8e-2 and res["s_vs_exact"] < 8e-2, (res, case)
+    else:
+        assert res["o_vs_exact"] < 5e-3 and res["s_vs_exact"] < 5e-3, (res, case)
+        assert res["o_vs_bf16model"] < 5e-4, (res, case)
+        # 1e-3, not the 1e-4 of the fixed cases: over 150 seeds two inputs (seeds 7 and 97) have ONE bf16 operand element of the
+        # decayed keys on a rounding tie that the kernel's fp32 exponent resolves the other way -- one state row of one head
+        # moves by 6e-3 of itself (4.9e-4 / 2.4e-4 of the whole state), every other row agrees to 1e-7, and the distance to
+        # the exact fp32 result is the model's own (3.22e-3 vs 3.23e-3)
+        assert res["s_vs_bf16model"] < (2.5e-3 if sd == torch.bfloat16 else 1e-3), (res, case)
+
+
 def test_gdn_long_call_uses_segments_and_matches_chained_calls():
     """Full-size property (H=16, T=8192+100 > one 4096-token workspace segment): one long call ==
     the same tokens fed as 256-token calls with the fp32 state carried (split invariance)."""
@@ -2198,6 +2229,75 @@ def test_swa_bulk_prefill_with_fused_rope_vs_oracle(T, seen, W, Hq, Hkv):
     slots = (seen + torch.arange(t_first, T)) % C
     got = kc[:, :, slots.to(DEV)].float().cpu()
     assert rms_rel(kr[:, :, t_first:], got) < 4e-3
+
+
+def _swa_random_case(seed):
+    import random
+    r = random.Random(seed)
+    W = r.choice([64, 96, 500, 1024, 4096])
+    C = W - 1
+    Hq, Hkv = r.choice([(2, 1), (4, 2), (16, 2)])
+    B = r.choice([1, 1, 2])
+    T = r.choice([r.randint(1, 70), r.randint(65, 700), r.randint(500, 1400)])
+    seen = r.choice([0, r.randint(1, C), r.randint(C, 4 * C), C, 2 * C - 1, r.randint(0, 3) * C + r.randint(0, 130)])
+    if Hq == 16:
+        T = min(T, 600)                                                    # keeps the CPU oracle at seconds
+    return B, T, Hq, Hkv, W, seen, r.random() < 0.5, r.random() < 0.6
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVL_SWA_FUZZ", "32"))))
+def test_swa_random_shapes_vs_oracle(seed):
+    """Randomised differential test of `ops.swa_forward` (every launch form: packed rows, 64- and 128-row workgroups, split and
+    single-split, ring / new / seam / wrap / tail tiles, with and without the fused M-RoPE and the folded append) against the
+    CPU oracle: ragged T, windows from 64 to 4096, rings empty / partly filled / wrapped several times.  IVL_SWA_FUZZ=N runs N
+    seeds (default 32)."""
+    from infinitevl_amd import ops
+    B, T, Hq, Hkv, W, seen, rope, append = _swa_random_case(seed)
+    d, C = 128, W - 1
+    g_ = torch.Generator().manual_seed(1000 + seed)
+    sn = lambda *sh: torch.randn(*sh, generator=g_).to(torch.bfloat16)      # noqa: E731
+    q, k, v = sn(B, T, Hq, d), sn(B, T, Hkv, d), sn(B, T, Hkv, d)
+    n_prev = oswa.n_prev_keys(W, seen)
+    hist = min(seen, 2 * C + 50)                                            # keys older than the ring's capacity are gone anyway
+    k_hist, v_hist = sn(B, hist, Hkv, d), sn(B, hist, Hkv, d)
+    qr, kr = q.float().transpose(1, 2), k.float().transpose(1, 2)
+    sec = [16, 24, 24]
+    if rope:
+        cos, sin = _mrope_tables(B, T, seen)
+        qr, kr = oswa.apply_mrope(qr, kr, cos.float().cpu(), sin.float().cpu(), sec)
+        qr, kr = qr.to(torch.bfloat16).float(), kr.to(torch.bfloat16).float()
+    k_all = torch.cat([k_hist[:, hist - n_prev:].float().transpose(1, 2), kr], dim=2)
+    v_all = torch.cat([v_hist[:, hist - n_prev:].float(), v.float()], dim=1).transpose(1, 2)
+    ref = oswa.swa_attention(qr, k_all, v_all, n_prev, W, d ** -0.5)
+    kc = torch.zeros(B, Hkv, C, d, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    pos_dev = torch.full((1,), seen - hist, dtype=torch.int64, device=DEV)
+    for a in range(0, hist, 333):
+        n = min(333, hist - a)
+        ops.swa_cache_append(k_hist[:, a:a + n].to(DEV), v_hist[:, a:a + n].to(DEV), kc, vc, pos_dev=pos_dev)
+        ops.counter_add(pos_dev, n)
+    kc0, vc0 = kc.clone(), vc.clone()
+    out = ops.swa_forward(q.to(DEV), k.to(DEV), v.to(DEV), window=W, scaling=d ** -0.5, k_cache=kc, v_cache=vc, pos_dev=pos_dev,
+                          rope=(cos, sin, sec) if rope else None, append=append)
+    torch.cuda.synchronize()
+    case = dict(B=B, T=T, Hq=Hq, Hkv=Hkv, W=W, seen=seen, rope=rope, append=append)
+    assert torch.isfinite(out.float()).all(), case
+    err = rms_rel(ref, out.float().cpu())
+    assert err < 5e-3, (err, case)
+    # per-row check: a single wrong row in a long call does not move the RMS over the whole tensor
+    row = ((ref - out.float().cpu()) ** 2).sum(-1).sqrt() / (ref ** 2).sum(-1).sqrt().clamp_min(1e-3)
+    assert float(row.max()) < 4e-2, (float(row.max()), case)
+    if append:
+        t_first = max(0, T - C)
+        slots = (seen + torch.arange(t_first, T)) % C
+        got = kc[:, :, slots.to(DEV)].float().cpu()
+        assert rms_rel(kr[:, :, t_first:], got) < 4e-3, case
+        assert torch.equal(vc[:, :, slots.to(DEV)].cpu(), v[:, t_first:].transpose(1, 2)), case
+        keep = torch.ones(C, dtype=torch.bool)
+        keep[slots] = False                                                 # every other slot is untouched
+        assert torch.equal(kc[:, :, keep.to(DEV)], kc0[:, :, keep.to(DEV)]) and torch.equal(vc[:, :, keep.to(DEV)], vc0[:, :, keep.to(DEV)]), case
+    else:
+        assert torch.equal(kc, kc0) and torch.equal(vc, vc0), case
 
 
 def test_swa_one_4096_token_call_equals_sixteen_256_token_calls():
