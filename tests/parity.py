@@ -161,7 +161,7 @@ def bf16_params(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3, window: int = 96,
                  seed: int = 0, stream_T: int = 70, fuse: bool = False, heads: int = 2,
-                 noise_floor: bool = False) -> Dict[str, float]:
+                 noise_floor: bool = False, schedule=None) -> Dict[str, float]:
     """4-layer stack (1 SWA + 3 GDN), real head dims: prefill (chunk path) -> streaming frame (chunk path,
     carry-in conv, ring wrap) -> decode steps (recurrent path), HIP modules vs oracle with bf16 activations."""
     from infinitevl_amd.harness import InfiniteVLTextStack
@@ -181,7 +181,10 @@ def layer_parity(device: str = "cuda:0", T_prefill: int = 130, n_decode: int = 3
     res: Dict[str, float] = {}
     pos = 0
     with torch.no_grad():
-        for name, T in [("prefill", T_prefill), ("stream", stream_T)] + [(f"decode{i}", 1) for i in range(n_decode)]:
+        calls = [("prefill", T_prefill), ("stream", stream_T)] + [(f"decode{i}", 1) for i in range(n_decode)]
+        if schedule is not None:                      # an arbitrary sequence of call lengths over one cache
+            calls = [(f"call{i}", int(T)) for i, T in enumerate(schedule)]
+        for name, T in calls:
             x = (torch.randn(1, T, hc.hidden_size, generator=g_) * 0.5).to(torch.bfloat16).float()
             pid = torch.arange(pos, pos + T)[None, None, :].expand(3, 1, T).contiguous()
             h_ref = omodel.text_stack(params, x, pid, oc, ocache, act_dtype=torch.bfloat16,

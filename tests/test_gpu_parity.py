@@ -706,6 +706,25 @@ def test_layer_stack_vs_oracle(fuse):
     assert r["gdn_state"] < 1.5e-2 and r["swa_keys"] < 6e-3, r
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVL_SCHED_FUZZ", "6"))))
+def test_layer_stack_random_call_schedules_vs_oracle(seed):
+    """A 4-layer stack (1 sliding + 3 linear layers, real head shapes) fed a RANDOM sequence of call lengths over one cache
+    -- 1-, 2- and 3-token calls (shorter than the convolution's carry), the 64 / 65 mode switch (Q7), ragged chunks, calls
+    longer than the window, ring wraps in the middle of a call -- against the oracle with the reference's rounding points,
+    call by call, and the cache at the end.  IVL_SCHED_FUZZ=N runs N seeds (default 6)."""
+    import random
+    r = random.Random(seed)
+    window = r.choice([64, 96, 300])
+    fuse = r.random() < 0.6
+    n = r.randint(5, 9)
+    schedule = [r.choice([1, 1, 2, 3, 5, 17, 63, 64, 65, 70, 130, 256, 333]) for _ in range(n)]
+    res = parity.layer_parity(DEV, window=window, seed=100 + seed, fuse=fuse, schedule=schedule)
+    case = dict(window=window, fuse=fuse, schedule=schedule)
+    for i in range(n):
+        assert res[f"call{i}"] < 1.5e-2, (res, case)
+    assert res["gdn_state"] < 1.5e-2 and res["swa_keys"] < 6e-3, (res, case)
+
+
 def _small_stack(window=96, seed=3, fuse=True):
     from infinitevl_amd.harness import InfiniteVLTextStack
     from oracle import model as omodel
