@@ -518,6 +518,48 @@ def test_vision_attention_real_shapes_vs_oracle(d, H):
         assert rms_rel(ref, got.float().cpu()) < 3e-3 and rms_rel(exact, got.float().cpu()) < 5e-3, (d, len(lens))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IVL_VISION_FUZZ", "12"))))
+def test_vision_attention_random_segmentations_vs_oracle(seed):
+    """Random segmentations of the patch axis (empty, one-patch, window-sized, ragged and frame-sized segments mixed in one
+    call; head_dim 80 / 64 / 128; with and without the rotary embedding in the loads; `max_seqlen` exact or generous) against
+    the oracle, per row as well as over the tensor.  IVL_VISION_FUZZ=N runs N seeds (default 12)."""
+    import random
+    from oracle import vision
+    from infinitevl_amd import ops
+    r = random.Random(seed)
+    d, H = r.choice([(80, 16), (80, 4), (64, 4), (128, 2)])
+    kind = r.choice(["windows", "frames", "mixed"])
+    pick = {"windows": lambda: r.choice([0, 1, 7, 16, 24, 36, 48, 63, 64]),
+            "frames": lambda: r.choice([65, 130, 500, 900, 1024, 1100]),
+            "mixed": lambda: r.choice([0, 1, 5, 64, 64, 64, 100, 129, 700, 1024])}[kind]
+    lens = [pick() for _ in range(r.randint(1, 24 if kind == "windows" else 5))]
+    if sum(lens) == 0:
+        lens.append(9)
+    S = sum(lens)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    g_ = torch.Generator().manual_seed(500 + seed)
+    qkv = bf(torch.randn(S, 3, H, d, generator=g_))
+    rope = r.random() < 0.7
+    max_len = max(lens) + r.choice([0, 0, 3, 200])
+    qd, kd, vd = (qkv.to(DEV)[:, i] for i in range(3))
+    qr, kr = qkv[:, 0], qkv[:, 1]
+    if rope:
+        pos_hw = torch.randint(0, 32, (S, 2), generator=g_)
+        cos, sin = vision.vision_rotary_tables(pos_hw, d)
+        got = ops.vision_window_attention(qd, kd, vd, cu.to(DEV), max_len, rope=(cos.to(DEV), sin.to(DEV)))
+        qr, kr = vision.apply_rotary_pos_emb_vision(qr, kr, cos, sin)
+    else:
+        got = ops.vision_window_attention(qd.contiguous(), kd.contiguous(), vd.contiguous(), cu.to(DEV), max_len)
+    torch.cuda.synchronize()
+    ref = vision.segment_attention(qr, kr, qkv[:, 2], cu.tolist(), p_round_dtype=torch.bfloat16)
+    case = dict(d=d, H=H, lens=lens, rope=rope, max_len=max_len)
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), case
+    assert rms_rel(ref, got) < 3e-3, (rms_rel(ref, got), case)
+    row = ((ref - got) ** 2).sum(-1).sqrt() / (ref ** 2).sum(-1).sqrt().clamp_min(1e-3)
+    assert float(row.max()) < 4e-2, (float(row.max()), case)
+
+
 def test_vision_attention_module_matches_reference():
     """InfiniteVLVisionAttention (same parameter names as the checkpoint) against the reference module's eager output,
     hidden 320 = 4 heads x 80; the projections are bf16 GEMMs here (fp32 in the fixture)."""
