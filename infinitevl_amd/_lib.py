@@ -137,10 +137,11 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_gdn_decode_step_fwd.restype = i
     lib.ivl_gdn_decode_step_fwd.argtypes = [vp, i64, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, i,
                                             vp, i, i, i, i, f, vp]
-    lib.ivl_gdn_decode_split_fwd.restype = i
-    lib.ivl_gdn_decode_split_fwd.argtypes = [vp, i64, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, f, vp]
-    lib.ivl_gdn_out_linear_small_m_fwd.restype = i
-    lib.ivl_gdn_out_linear_small_m_fwd.argtypes = [vp, vp, i64, vp, f, i, vp, i64, i, i, vp, vp, vp, vp, vp, i, i, i, vp]
+    if path is None or hasattr(lib, "ivl_gdn_decode_split_fwd"):  # (a developer A/B against a pre-v10 build lacks them)
+        lib.ivl_gdn_decode_split_fwd.restype = i
+        lib.ivl_gdn_decode_split_fwd.argtypes = [vp, i64, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, i, i, i, i, f, vp]
+        lib.ivl_gdn_out_linear_small_m_fwd.restype = i
+        lib.ivl_gdn_out_linear_small_m_fwd.argtypes = [vp, vp, i64, vp, f, i, vp, i64, i, i, vp, vp, vp, vp, vp, i, i, i, vp]
     lib.ivl_linear_swiglu_small_m_fwd.restype = i
     lib.ivl_linear_swiglu_small_m_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.ivl_norm_linear_small_m_fwd.restype = i
