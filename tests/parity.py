@@ -68,6 +68,8 @@ def gdn_op_parity(device: str, mode: str, B: int, T: int, H: int, seed: int = 0,
         o_bf, s_bf = ogdn.gdn_recurrent(q, k, v, g, beta, initial_state=h0, qk_round_dtype=torch.bfloat16)
     res["o_vs_bf16model"] = rms_rel(o_bf.to(torch.bfloat16).float(), o.float())
     res["s_vs_bf16model"] = rms_rel(s_bf, ht.float())
+    res["o_bf16model_vs_exact"] = rms_rel(o_ex, o_bf.to(torch.bfloat16).float())      # the reference-rounding model's own distance
+    res["s_bf16model_vs_exact"] = rms_rel(s_ex, s_bf)
     if mma_dtype is not None and mode == "chunk":
         o_f8, s_f8 = ogdn.gdn_chunk(q, k, v, g, beta, initial_state=h0, rounding=torch.bfloat16, mma_rounding=torch.float8_e4m3fn)
         res["o_vs_fp8model"] = rms_rel(o_f8.to(torch.bfloat16).float(), o.float())

@@ -131,16 +131,19 @@ def test_gdn_random_shapes_vs_oracle(seed):
                                mma_dtype="fp8_e4m3" if fp8 else None)
     case = dict(B=B, T=T, H=H, h0=h0, sd=str(sd), inplace=inplace, fp8=fp8)
     assert res["finite"] == 1.0, (res, case)
+    # Bounds of the fixed cases, widened where 750 seeds showed what a random input can do WITHOUT a defect (seeds 7, 97 and
+    # 446 taken apart on the GPU per head, row and chunk): (a) a single operand element on a rounding tie resolved the other way by the kernel's fp32 summation
+    # order moves one state row (bf16: seeds 7, 97: 2.4e-4 / 4.9e-4 of the state) or one chunk of one head (e4m3, 2^-4 per
+    # flip: seed 446: 1.1e-2 inside chunk 1 of head 10, nothing before, nothing after, state untouched = 1.4e-3 of the
+    # output; bf16 at T = 19, where one flipped row weighs more: seed 189, 6.7e-4, state 6.6e-5); (b) at T = 3 the reference-rounding model itself is 6.2e-3 from exact fp32
+    # (seed 367: the kernel equals that model bit for bit) -- so the distance to exact is bounded against the model's own.
     if fp8:
-        assert res["o_vs_fp8model"] < 1e-3 and res["s_vs_fp8model"] < (3e-3 if sd == torch.bfloat16 else 1e-3), (res, case)
+        assert res["o_vs_fp8model"] < 3e-3 and res["s_vs_fp8model"] < 3e-3, (res, case)
         assert res["o_vs_exact"] < 8e-2 and res["s_vs_exact"] < 8e-2, (res, case)
     else:
-        assert res["o_vs_exact"] < 5e-3 and res["s_vs_exact"] < 5e-3, (res, case)
-        assert res["o_vs_bf16model"] < 5e-4, (res, case)
-        # 1e-3, not the 1e-4 of the fixed cases: over 150 seeds two inputs (seeds 7 and 97) have ONE bf16 operand element of the
-        # decayed keys on a rounding tie that the kernel's fp32 exponent resolves the other way -- one state row of one head
-        # moves by 6e-3 of itself (4.9e-4 / 2.4e-4 of the whole state), every other row agrees to 1e-7, and the distance to
-        # the exact fp32 result is the model's own (3.22e-3 vs 3.23e-3)
+        assert res["o_vs_exact"] < max(5e-3, 1.1 * res["o_bf16model_vs_exact"] + 2e-4), (res, case)
+        assert res["s_vs_exact"] < max(5e-3, 1.1 * res["s_bf16model_vs_exact"] + 2e-4), (res, case)
+        assert res["o_vs_bf16model"] < 1e-3, (res, case)
         assert res["s_vs_bf16model"] < (2.5e-3 if sd == torch.bfloat16 else 1e-3), (res, case)
 
 
