@@ -42,7 +42,19 @@ __device__ __forceinline__ float conv1(const bf16_t* xrow, int col, const bf16_t
   return bf_round(a * sigmoidf_(a));
 }
 
-__global__ __launch_bounds__(64 * DNW) void gdn_decode_step_kernel(DecParams p) {
+// The fields a workgroup needs for its FIRST loads (state rows, the token's projection row, conv taps) are passed a second time as
+// leading scalar / pointer parameters: those are preloaded into SGPRs at wave launch (Makefile: -amdgpu-kernarg-preload-count=16,
+// exactly these 16 dwords), a by-value struct is not -- the kernel's first loads no longer wait for a cold read of its own kernarg
+// segment.  DEC_HEAD_APPLY overrides the struct's copies, so the rest of the kernel reads `p` as before.
+#define DEC_HEAD_PARAMS void* hd_state, int hd_state_dtype, int hd_H, const bf16_t* hd_proj, long long hd_ld, int hd_col_q, int hd_col_k, \
+                        int hd_col_v, const bf16_t* hd_wq, const bf16_t* hd_wk
+#define DEC_HEAD_ARGS(p) (p).state, (p).state_dtype, (p).H, (p).proj, (p).ld, (p).col_q, (p).col_k, (p).col_v, (p).wq, (p).wk
+#define DEC_HEAD_APPLY(p)                                                                                                    \
+  (p).state = hd_state; (p).state_dtype = hd_state_dtype; (p).H = hd_H; (p).proj = hd_proj; (p).ld = hd_ld; (p).col_q = hd_col_q; \
+  (p).col_k = hd_col_k; (p).col_v = hd_col_v; (p).wq = hd_wq; (p).wk = hd_wk
+
+__global__ __launch_bounds__(64 * DNW) void gdn_decode_step_kernel(DEC_HEAD_PARAMS, DecParams p) {
+  DEC_HEAD_APPLY(p);
   __shared__ __attribute__((aligned(16))) float s_k[DK], s_q[DK], s_v[DV];
   __shared__ __attribute__((aligned(16))) float s_red[DNW][2][DV];
   __shared__ float s_part[4][2];
@@ -198,7 +210,8 @@ __device__ __forceinline__ float conv1_ro(const bf16_t* xrow, int col, const bf1
   return bf_round(a * sigmoidf_(a));
 }
 
-__global__ __launch_bounds__(256) void gdn_decode_split_kernel(DecParams p) {
+__global__ __launch_bounds__(256) void gdn_decode_split_kernel(DEC_HEAD_PARAMS, DecParams p) {
+  DEC_HEAD_APPLY(p);
   __shared__ __attribute__((aligned(16))) float s_k[DK], s_q[DK], s_v[DSC];
   __shared__ __attribute__((aligned(16))) float s_red[8][2][DSC];
   __shared__ float s_part[4][2];
@@ -328,7 +341,7 @@ extern "C" int ivl_gdn_decode_step_fwd(const void* proj, int64_t ld, int col_q, 
   p.cq = (bf16_t*)conv_state_q; p.ck = (bf16_t*)conv_state_k; p.cv = (bf16_t*)conv_state_v;
   p.A_log = A_log; p.dt_bias = dt_bias; p.norm_w = (const bf16_t*)norm_weight; p.eps = eps;
   p.state = state; p.state_dtype = state_dtype; p.y = (bf16_t*)y; p.H = H; p.scale = scale;
-  hipLaunchKernelGGL(gdn_decode_step_kernel, dim3(B * H), dim3(64 * DNW), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gdn_decode_step_kernel, dim3(B * H), dim3(64 * DNW), 0, (hipStream_t)stream, DEC_HEAD_ARGS(p), p);
   return check_launch("ivl_gdn_decode_step_fwd");
 }
 
@@ -352,6 +365,6 @@ extern "C" int ivl_gdn_decode_split_fwd(const void* proj, int64_t ld, int col_q,
   p.cq = (bf16_t*)conv_state_q; p.ck = (bf16_t*)conv_state_k; p.cv = (bf16_t*)conv_state_v;
   p.A_log = A_log; p.dt_bias = dt_bias; p.norm_w = nullptr; p.eps = 0.f;
   p.state = state; p.state_dtype = state_dtype; p.y = (bf16_t*)o_raw; p.H = H; p.scale = scale;
-  hipLaunchKernelGGL(gdn_decode_split_kernel, dim3(B * H * DSQ), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gdn_decode_split_kernel, dim3(B * H * DSQ), dim3(256), 0, (hipStream_t)stream, DEC_HEAD_ARGS(p), p);
   return check_launch("ivl_gdn_decode_split_fwd");
 }

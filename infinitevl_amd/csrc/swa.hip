@@ -129,7 +129,7 @@ __device__ __forceinline__ void rope_pair(u32x4& lo, u32x4& hi, const bf16_t* co
 }
 
 template <bool PACK, int QG>
-__global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
+__global__ __launch_bounds__(256, 2) void swa_fwd_kernel(const long long* pos_dev, SwaParams p) {   // (pos_dev: see swa_prefill_kernel)
   __shared__ __attribute__((aligned(16))) unsigned char smem[SWA_LDS_BYTES];
   constexpr int QT = SWA_QT * QG;      // query rows per workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void swa_fwd_kernel(SwaParams p) {
 #endif
   IVL_TVAR(tr_b1); IVL_TVAR(tr_st); IVL_TVAR(tr_qk); IVL_TVAR(tr_sm); IVL_TVAR(tr_pv);
 
-  const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
+  const long long pos = pos_dev ? *pos_dev : p.pos;
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
   const int n_extra = p.T_new - p.T;
   const int n_prev = n_ring + n_extra;
@@ -523,7 +523,10 @@ constexpr int P8_STAGES = 4;                                      // tile t in s
 constexpr int P8_LDS_BYTES = P8_STAGES * P8_STAGE;                // 128 KB
 static_assert(PF_ML_OFF + 128 * 8 <= P8_LDS_BYTES, "merge image must fit the K/V stages");
 
-__global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill_kernel(SwaParams p) {
+// `pos_dev` (= p.pos_dev) is a parameter of its own IN FRONT of the struct: leading scalar / pointer parameters are preloaded into
+// SGPRs at wave launch (Makefile: -amdgpu-kernarg-preload-count; a by-value struct is not), and the position load is the head of
+// the kernel's start-up chain (kernarg -> position -> tile addresses -> first DMA): it no longer waits for the kernarg s_load.
+__global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill_kernel(const long long* pos_dev, SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[P8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi5 = lane >> 5, l15 = lane & 15;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill_kernel(SwaParams p)
   // the position comes through a vector load (the pointer is not provably read-only): everything derived from it -- ring geometry,
   // tile kinds, DMA addresses, the dead-tile tests -- must live in SGPRs, or every test on it becomes a lane-mask operation and
   // every address a 64-bit VALU chain (measured: 480-1,060 cycles per tile for the four DMA pieces of a wave)
-  const long long pos_v = p.pos_dev ? *p.pos_dev : p.pos;
+  const long long pos_v = pos_dev ? *pos_dev : p.pos;
   const long long pos = (long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)pos_v >> 32)) << 32) |
                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)pos_v));
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
@@ -987,7 +990,7 @@ __device__ __forceinline__ f32x4 mma_fp8(u32x2 a, u32x2 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
+__global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(const long long* pos_dev, SwaParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[F8_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(256, 2) void swa_decode_fp8_kernel(SwaParams p) {
   const int bz = blockIdx.x / p.Hkv;
   const int b = bz / p.nsplit, split = bz % p.nsplit;
 
-  const long long pos = p.pos_dev ? *p.pos_dev : p.pos;
+  const long long pos = pos_dev ? *pos_dev : p.pos;
   const int n_ring = p.C > 0 ? (int)(pos < (long long)p.C ? pos : (long long)p.C) : 0;
   const int n_extra = p.T_new - p.T;
   const int n_prev = n_ring + n_extra;
@@ -1441,11 +1444,11 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   }
   p.n_qtiles = prefill ? (rows + PF_QT - 1) / PF_QT : (rows + SWA_QT * qg - 1) / (SWA_QT * qg);
   dim3 grid(p.n_qtiles * (pack ? a->Hkv : a->Hq) * a->B * nsplit);
-  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(P8_THREADS), 0, st, p);
+  if (prefill) hipLaunchKernelGGL(swa_prefill_kernel, grid, dim3(P8_THREADS), 0, st, p.pos_dev, p);
   else if (pack && a->mma_dtype == IVL_FP8_E4M3)
-    hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p);
-  else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(swa_decode_fp8_kernel, dim3(a->Hkv * a->B * nsplit), dim3(256), 0, st, p.pos_dev, p);
+  else if (pack) hipLaunchKernelGGL((swa_fwd_kernel<true, 1>), grid, dim3(256), 0, st, p.pos_dev, p);
+  else hipLaunchKernelGGL((swa_fwd_kernel<false, 1>), grid, dim3(256), 0, st, p.pos_dev, p);
   int rc = check_launch("ivl_swa_fwd");
   if (rc != IVL_OK) return rc;
   AppendArgs ap;
