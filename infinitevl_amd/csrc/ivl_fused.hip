@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_strided_kernel(
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o8[i] = xf[i] * rstd * wf[i] * gf[i] * sigmoidf_(gf[i]);
-    *(u32x4*)(y + r * 256 + lane32 * 8) = pack8(o8);
+    store_out16(y + r * 256 + lane32 * 8, pack8(o8));
   }
 }
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(
         unpack8(*(const u32x4*)(residual + row * N + v * 8), rv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) hv[it][i] = bf_round(hv[it][i] + rv[i]);
-        *(u32x4*)(h_out + row * N + v * 8) = pack8(hv[it]);
+        store_out16(h_out + row * N + v * 8, pack8(hv[it]));
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) ss = fmaf(hv[it][i], hv[it][i], ss);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(
       unpack8(wraw[it], wv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o8[i] = wv[i] * bf_round(hv[it][i] * rstd);
-      *(u32x4*)(y + row * N + v * 8) = pack8(o8);
+      store_out16(y + row * N + v * 8, pack8(o8));
     }
   }
 }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
     unpack8(*(const u32x4*)(gu + r * 2 * I + I + v * 8), b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = bf_round(a[i] * sigmoidf_(a[i])) * b[i];
-    *(u32x4*)(y + r * I + v * 8) = pack8(o);
+    store_out16(y + r * I + v * 8, pack8(o));
   }
 }
 
