@@ -1804,12 +1804,12 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
       if (tc0 + GC <= T) {               // full chunk (wave-uniform): four unconditional 8-byte row stores
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          *(u32x2*)(orow + m * ostep) = u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
+          store_out8(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
       } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           if (tc0 + 16 * m + j < T)
-            *(u32x2*)(orow + m * ostep) = u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)};
+            store_out8(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
       }
       orow += 4 * ostep;
       IVL_T(o4);

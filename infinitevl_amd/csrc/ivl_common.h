@@ -28,11 +28,22 @@ __device__ __forceinline__ void store_out16(void* p, u32x4 v) {
 #if IVL_OUT_STORE == 1
   __builtin_nontemporal_store(v, (u32x4*)p);
 #elif IVL_OUT_STORE == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // (the s_nop: a store of more than 8 bytes reads its data registers after issue, and hipcc does not pad an asm statement --
+  //  without it the next instruction may overwrite them first: cdna_hip_programming.md section 5.7)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *(u32x4*)p = v;
 #endif
 }
+typedef __attribute__((ext_vector_type(2))) unsigned int ivl_u32x2_t;
+__device__ __forceinline__ void store_out8(void* p, ivl_u32x2_t v) {
+#if IVL_OUT_STORE == 2
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *(ivl_u32x2_t*)p = v;
+#endif
+}
+
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned int)x) << 16); }

@@ -942,8 +942,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void swa_prefill_kernel(const long l
         const f32x4 x = *(const f32x4*)src, y = *(const f32x4*)(src + 16);
         const long long orow = p.nsplit == 1 ? ((long long)b * p.T + t) * p.Hq + hq
                                              : (((long long)b * p.nsplit + split) * p.T + t) * p.Hq + hq;
-        *(u32x4*)(dst + orow * SWA_D + 8 * c) =
-            u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+        store_out16(dst + orow * SWA_D + 8 * c,
+                    u32x4{pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(y[0], y[1]), pack2bf(y[2], y[3])});
       }
     }
     if (p.nsplit > 1 && tid < PF_QT && tile_row0 + tid < p.T) {
@@ -1166,8 +1166,8 @@ __global__ __launch_bounds__(256) void swa_rope_prepass_kernel(const bf16_t* __r
     u32x4 lo = *(const u32x4*)(src + 8 * c), hi = *(const u32x4*)(src + 8 * c + 64);
     rope_pair(lo, hi, rcos, rsin, plane, bt * SWA_D, 8 * c, rs0, rs1);
     bf16_t* dst = is_q ? q_out + (bt * Hq + h) * SWA_D : k_out + (bt * Hkv + (h - Hq)) * SWA_D;
-    *(u32x4*)(dst + 8 * c) = lo;
-    *(u32x4*)(dst + 8 * c + 64) = hi;
+    store_out16(dst + 8 * c, lo);
+    store_out16(dst + 8 * c + 64, hi);
   }
 }
 
