@@ -1801,15 +1801,22 @@ __device__ __forceinline__ void gdn_chunk_scan_body(
       if constexpr (SYNC == 2) {
         if (__builtin_amdgcn_readfirstlane(gate_abort) != 0u) return;   // a later chunk's record never came: stop storing
       }
+      // the step shape (single launch, SYNC == 1) writes its 2 MB of o through (`sc0 sc1`: they leave during the kernel instead of in
+      // its end-of-kernel write-back: 17.2 -> 16.6 us in step); a long call's 33 MB written through back up into the output waves
+      // (in-call 101.7 -> 118 us at T = 4096): plain stores there
+      auto put = [&](bf16_t* dst, u32x2 w) __attribute__((always_inline)) {
+        if constexpr (SYNC == 1) store_out8(dst, w);
+        else *(u32x2*)dst = w;
+      };
       if (tc0 + GC <= T) {               // full chunk (wave-uniform): four unconditional 8-byte row stores
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          store_out8(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
+          put(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
       } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           if (tc0 + 16 * m + j < T)
-            store_out8(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
+            put(orow + m * ostep, u32x2{pack2bf(accO[m][0] * scale, accO[m][1] * scale), pack2bf(accO[m][2] * scale, accO[m][3] * scale)});
       }
       orow += 4 * ostep;
       IVL_T(o4);

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
                                                       long long rows, int I) {
   const int nvec = I / 8;
   const long long total = rows * nvec;
+  // up to 32 MB of output (the 256-token step: 5.6 MB) is written through (store_out16: -0.1 us in step); the 90 MB of a
+  // 4096-token call back up behind the memory side when written through (42.8 -> 45.7 us in call): plain stores there
+  const bool write_through = total * 16 <= (32ll << 20);
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     int v;
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const bf16_t* __restrict_
     unpack8(*(const u32x4*)(gu + r * 2 * I + I + v * 8), b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = bf_round(a[i] * sigmoidf_(a[i])) * b[i];
-    store_out16(y + r * I + v * 8, pack8(o));
+    if (write_through) store_out16(y + r * I + v * 8, pack8(o));
+    else *(u32x4*)(y + r * I + v * 8) = pack8(o);
   }
 }
 
