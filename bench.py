@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the bulk-prefill leg (configs[3]: 4096-token calls at >= 128K context)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (e4m3) leg (BASELINE.json configs[4])")
+    ap.add_argument("--cfg3-tokens", type=int, default=0,
+                    help="configs[3] leg: 0 (default) = 2 + 8 calls of 4096 tokens continuing from the reached context; N > 0 = a FRESH "
+                         "sequence of N tokens per rank in 4096-token calls from position 0 (524288 = the full configs[3] sequence, 128 calls)")
     ap.add_argument("--sp-tokens", type=int, default=4096, help="N > 1: tokens per rank of the sequence-parallel prefill leg")
     ap.add_argument("--no-sp", action="store_true", help="N > 1: skip the sequence-parallel prefill leg (SURVEY.md 8f-4)")
     return ap.parse_args()
@@ -511,6 +514,16 @@ def main():
     infinitevl_amd.load_library()
     from infinitevl_amd.harness import GraphedDecode, GraphedStep, InfiniteVLTextConfig, InfiniteVLTextStack
 
+    def all_ok(ok: bool) -> bool:
+        """Exchange an ok flag (all_reduce MIN) after every stage that can fail on ONE rank (an allocation, a kernel error), BEFORE
+        the next collective: a rank that raised then does not leave the others blocked in a barrier / all_reduce -- every rank
+        skips the rest of that leg and the error is recorded."""
+        if world == 1:
+            return ok
+        t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MIN)
+        return bool(int(t_.item()))
+
     cfg = InfiniteVLTextConfig(sliding_window=args.window, num_hidden_layers=args.layers)
     with torch.device(device):
         torch.set_default_dtype(torch.bfloat16)
@@ -608,11 +621,6 @@ def main():
         # an ok flag (all_reduce MIN) BEFORE the next collective, so a rank that raised does not leave the others blocked in a
         # barrier / broadcast: all ranks then skip the rest of the leg and the error is recorded.  The headline above is
         # already measured; the leg never raises.
-        def all_ok(ok: bool) -> bool:
-            t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-            torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MIN)
-            return bool(int(t_.item()))
-
         Ts = args.sp_tokens
         err, xs_all, cache_sp, lg_sp, sp_ms = None, None, None, None, []
         first, last_tok = ivd.segment_bounds(world * Ts, rank, world)
@@ -625,19 +633,25 @@ def main():
         if not all_ok(err is None):
             err = err or "setup failed on another rank"
         else:
-            try:
-                with torch.no_grad():
-                    for rep in range(2):                                  # rep 0: communicator set-up and warm-up, rep 1: timed
-                        cache_sp.reset()
-                        ivd.barrier()
-                        torch.cuda.synchronize()
-                        tA = time.perf_counter()
+            for rep in range(2):                                          # rep 0: communicator set-up and warm-up, rep 1: timed
+                cache_sp.reset()
+                ivd.barrier()
+                torch.cuda.synchronize()
+                tA = time.perf_counter()
+                try:
+                    with torch.no_grad():
                         _, lg_sp = ivd.sequence_parallel_prefill(model, xs_all[:, first:last_tok], cache_sp, first, rank, world, logits_to_keep=1)
-                        torch.cuda.synchronize()
-                        ivd.barrier()
-                        sp_ms.append(ivd.max_over_ranks((time.perf_counter() - tA) * 1e3, device))
-            except Exception as e:           # noqa: BLE001   (a failure INSIDE the hand-off is a communicator failure: nothing to exchange)
-                err = f"prefill: {type(e).__name__}: {e}"
+                    torch.cuda.synchronize()
+                except Exception as e:       # noqa: BLE001
+                    err = f"prefill: {type(e).__name__}: {e}"
+                # every rank exchanges the flag here, raised or not, BEFORE the barrier / MAX-reduce below: a rank
+                # that failed in its own kernels after the hand-off (OOM, IVL_ERR_SYNC) must not leave the healthy ranks alone in
+                # a collective.  (A failure INSIDE the hand-off itself is a communicator failure; only its time-out ends that.)
+                if not all_ok(err is None):
+                    err = err or "the prefill failed on another rank"
+                    break
+                ivd.barrier()
+                sp_ms.append(ivd.max_over_ranks((time.perf_counter() - tA) * 1e3, device))
         check = {"equal": None, "max_abs_diff": None}
         if err is None:
             if rank == world - 1:                                         # the single-rank run of the same call sequence
@@ -714,108 +728,188 @@ def main():
         model.set_mma_dtype(None)
         del step8, dec8, cache8
 
-    # ---- configs[3] leg, single-GPU half (rank 0, N=1; reported beside the headline): bulk prefill of ONE long sequence in
-    #      4096-token calls over a FULL 4096-key ring, continuing from the >= 128K-token context the legs above left in `cache`
-    #      (SURVEY.md 8d cfg4 "128 calls of T=4096, state carried"; reference claim README.md:51).  Eager launches.
+    # ---- configs[3] leg (EVERY rank: "512K-token long-context prefill, batch=8 sharded data-parallel across 8 x MI355X" = one
+    #      sequence per GPU; reported beside the headline): bulk prefill of one long sequence per rank in 4096-token calls over a
+    #      FULL 4096-key ring with carried GDN state (SURVEY.md 8d cfg4 "128 calls of T=4096, state carried"; reference claim
+    #      README.md:51).  Eager launches.  Default: 2 + 8 calls continuing from the >= 128K-token context the legs above left in
+    #      `cache`; --cfg3-tokens N: a FRESH sequence of N tokens per rank from position 0 (524288 = the whole configs[3] job).
+    #      The timed region is bracketed by barriers, the slowest rank defines it (MAX over ranks), the aggregate is all ranks'
+    #      tokens over that time, and the last-position logits of all sequences are gathered ONCE at the end (the path's only
+    #      collective).
     cfg3 = None
-    if rank == 0 and world == 1 and not args.no_cfg3:
-        Tb, n_warm, n_timed = 4096, 2, 8
-        ctx0 = cache.get_seq_length()
-        xb = (torch.randn(1, Tb, cfg.hidden_size, device=device, generator=gen) * 0.02).to(torch.bfloat16)
-        times3 = []
-        with torch.no_grad():
-            for r in range(n_warm + n_timed):
-                start3 = cache.get_seq_length()
-                pid3 = torch.arange(start3, start3 + Tb, device=device)[None, None, :].expand(3, 1, Tb).contiguous()
-                torch.cuda.synchronize()
-                tA = time.perf_counter()
-                _, lg3 = model(inputs_embeds=xb, position_ids=pid3, past_key_values=cache, logits_to_keep=1)
-                torch.cuda.synchronize()
-                if r >= n_warm:
-                    times3.append(time.perf_counter() - tA)
-        mean3 = sum(times3) / len(times3)
-        # per-call kernel times of one more call of the same kind (torch.profiler activity records of the eager launches): the
-        # in-scope kernels of a 4096-token call over the full ring, grouped
-        kern3 = None
+    if not args.no_cfg3:
+        Tb = 4096
+        fresh = args.cfg3_tokens > 0
+        n_warm, n_timed = (1, max(1, args.cfg3_tokens // Tb)) if fresh else (2, 8)
+        err3, xb, cache3, lg3, times3, mem_marks = None, None, None, None, [], []
         try:
-            import collections
-            from torch.profiler import ProfilerActivity, profile
-            start3 = cache.get_seq_length()
-            pid3 = torch.arange(start3, start3 + Tb, device=device)[None, None, :].expand(3, 1, Tb).contiguous()
-            torch.cuda.synchronize()
-            with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof3:
-                model(inputs_embeds=xb, position_ids=pid3, past_key_values=cache, logits_to_keep=1)
+            xb = (torch.randn(1, Tb, cfg.hidden_size, device=device, generator=gen) * 0.02).to(torch.bfloat16)
+            cache3 = model.allocate_inference_cache(1) if fresh else cache
+        except Exception as e:               # noqa: BLE001
+            err3 = f"setup: {type(e).__name__}: {e}"
+        region3 = None
+        if not all_ok(err3 is None):
+            err3 = err3 or "setup failed on another rank"
+        else:
+            def call3():
+                start3 = cache3.get_seq_length()
+                pid3 = torch.arange(start3, start3 + Tb, device=device)[None, None, :].expand(3, 1, Tb).contiguous()
+                return model(inputs_embeds=xb, position_ids=pid3, past_key_values=cache3, logits_to_keep=1)[1]
+            try:
+                with torch.no_grad():
+                    for _ in range(n_warm):              # M = 4096 library GEMMs are tuned / loaded here, not in the timed calls
+                        call3()
+                    if fresh:
+                        cache3.reset()
+                    torch.cuda.synchronize()
+            except Exception as e:           # noqa: BLE001
+                err3 = f"warm-up: {type(e).__name__}: {e}"
+            if not all_ok(err3 is None):
+                err3 = err3 or "warm-up failed on another rank"
+            else:
+                ctx0 = cache3.get_seq_length()
+                ivd.barrier()
                 torch.cuda.synchronize()
-            grp = collections.defaultdict(lambda: [0.0, 0])
-            per3 = collections.defaultdict(lambda: [0.0, 0])          # the path's own kernels, by name: duration INSIDE the call
-            for ev in prof3.events():
-                if "cuda" not in str(ev.device_type).lower():
-                    continue
-                nm = ev.name
-                dur = float(ev.device_time if hasattr(ev, "device_time") else ev.cuda_time)
-                if "ivl::" in nm:
-                    short = nm.split("(")[0].replace("void ", "").replace("ivl::", "")
-                    per3[short][0] += dur
-                    per3[short][1] += 1
-                key = ("gdn_chunk (pre-pass + scan)" if "gdn_chunk" in nm else
-                       "swa (rope pre-pass + prefill + combine/append)" if ("swa_" in nm) else
-                       "gated norm / add+norm / SwiGLU gate / rope tables" if "ivl::" in nm else "library GEMMs and torch glue")
-                grp[key][0] += dur
-                grp[key][1] += 1
-            kern3 = {k: {"ms_per_call": round(v[0] * 1e-3, 4), "launches": v[1]} for k, v in grp.items()}
-            kern3["by_kernel_us"] = {k: {"avg_us": round(v[0] / v[1], 2), "launches": v[1]} for k, v in sorted(per3.items())}
-        except Exception as e:                       # the breakdown is optional: never lose the leg over the profiler
-            kern3 = {"error": repr(e)}
-        cfg3 = {"workload": "configs[3], one GPU's share: bulk prefill of one long sequence in 4096-token calls (eager launches) over a "
-                            "full 4096-key ring with carried GDN state, starting at the context the streaming + decode legs reached",
-                "context_start": ctx0 + n_warm * Tb, "context_end": cache.get_seq_length(), "calls_timed": n_timed,
-                "tokens_per_call": Tb, "ms_per_call": mean3 * 1e3, "ms_per_call_min": min(times3) * 1e3,
-                "prefill_tok_s": Tb / mean3, "logits_finite": bool(torch.isfinite(lg3.float()).all()),
-                "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                "kernel_ms_in_one_call": kern3}
-        del xb
+                tR = time.perf_counter()
+                try:
+                    with torch.no_grad():
+                        for r in range(n_timed):
+                            tA = time.perf_counter()
+                            lg3 = call3()
+                            torch.cuda.synchronize()
+                            times3.append(time.perf_counter() - tA)
+                            if r in (1, n_timed - 1):    # after the ring is full (second call) and at the end: constant memory
+                                mem_marks.append(torch.cuda.memory_allocated(device))
+                except Exception as e:       # noqa: BLE001
+                    err3 = f"call {len(times3)}: {type(e).__name__}: {e}"
+                if not all_ok(err3 is None):
+                    err3 = err3 or "a timed call failed on another rank"
+                else:
+                    ivd.barrier()
+                    region3 = ivd.max_over_ranks(time.perf_counter() - tR, device)
+        if err3 is not None:
+            cfg3 = {"error": err3, "failed": True}
+        else:
+            mean3 = sum(times3) / len(times3)
+            full = times3[1:] if fresh and len(times3) > 1 else times3     # fresh: the first call is causal over an empty ring
+            per_rank_ms = [mean3 * 1e3]
+            gathered3 = None
+            if world > 1:
+                box = [None] * world
+                torch.distributed.all_gather_object(box, mean3 * 1e3)
+                per_rank_ms = [float(v) for v in box]
+                tg3 = time.perf_counter()
+                gathered3 = ivd.gather_last_logits(lg3[:, -1].float().contiguous(), [1] * world)
+                torch.cuda.synchronize()
+                gather3_ms = ivd.max_over_ranks((time.perf_counter() - tg3) * 1e3, device)
+                assert tuple(gathered3.shape) == (world, cfg.vocab_size), gathered3.shape
+            fin3 = bool(torch.isfinite(lg3.float()).all()) if gathered3 is None else bool(torch.isfinite(gathered3).all())
+            # per-call kernel times of one more call of the same kind (rank 0; torch.profiler activity records of the eager
+            # launches): the in-scope kernels of a 4096-token call over the full ring, grouped
+            kern3 = None
+            if rank == 0 and not args.no_kernel_timing:
+                try:
+                    import collections
+                    from torch.profiler import ProfilerActivity, profile
+                    torch.cuda.synchronize()
+                    with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof3:
+                        call3()
+                        torch.cuda.synchronize()
+                    grp = collections.defaultdict(lambda: [0.0, 0])
+                    per3 = collections.defaultdict(lambda: [0.0, 0])      # the path's own kernels, by name: duration INSIDE the call
+                    for ev in prof3.events():
+                        if "cuda" not in str(ev.device_type).lower():
+                            continue
+                        nm = ev.name
+                        dur = float(ev.device_time if hasattr(ev, "device_time") else ev.cuda_time)
+                        if "ivl::" in nm:
+                            short = nm.split("(")[0].replace("void ", "").replace("ivl::", "")
+                            per3[short][0] += dur
+                            per3[short][1] += 1
+                        key = ("gdn_chunk (pre-pass + scan)" if "gdn_chunk" in nm else
+                               "swa (rope pre-pass + prefill + combine/append)" if ("swa_" in nm) else
+                               "gated norm / add+norm / SwiGLU gate / rope tables" if "ivl::" in nm else "library GEMMs and torch glue")
+                        grp[key][0] += dur
+                        grp[key][1] += 1
+                    kern3 = {k: {"ms_per_call": round(v[0] * 1e-3, 4), "launches": v[1]} for k, v in grp.items()}
+                    kern3["by_kernel_us"] = {k: {"avg_us": round(v[0] / v[1], 2), "launches": v[1]} for k, v in sorted(per3.items())}
+                except Exception as e:                   # the breakdown is optional: never lose the leg over the profiler
+                    kern3 = {"error": repr(e)}
+            cfg3 = {"workload": f"configs[3]: bulk prefill of ONE long sequence PER GPU ({world} sequence(s), batch-sharded, no data-path "
+                                f"collective) in 4096-token calls (eager launches) over a full 4096-key ring with carried GDN state; "
+                                + (f"a fresh {n_timed * Tb}-token sequence per rank from position 0" if fresh else
+                                   "continuing from the context the streaming + decode legs reached")
+                                + "; last-position logits gathered once at the end",
+                    "n_gpus": world, "sequences": world, "context_start": ctx0, "context_end": cache3.get_seq_length(), "calls_timed": n_timed,
+                    "tokens_per_call": Tb, "tokens_timed_all_ranks": world * n_timed * Tb,
+                    "ms_per_call": max(per_rank_ms), "ms_per_call_min": min(times3) * 1e3,
+                    "ms_per_call_full_ring": sum(full) / len(full) * 1e3, "per_rank_ms": [round(v, 3) for v in per_rank_ms],
+                    "region_ms_max_over_ranks": region3 * 1e3,
+                    # the aggregate over all ranks: every rank's tokens over the slowest rank's barrier-to-barrier time
+                    "aggregate_tok_s": world * n_timed * Tb / region3,
+                    "prefill_tok_s": Tb / mean3, "per_gpu_tok_s": n_timed * Tb / region3,
+                    "logits_finite": fin3,
+                    "gathered_logits_shape": list(gathered3.shape) if gathered3 is not None else [1, cfg.vocab_size],
+                    "gather_ms": gather3_ms if gathered3 is not None else None,
+                    "mem_allocated_gib_after_ring_fill_and_at_end": [round(m / 2 ** 30, 3) for m in mem_marks],
+                    "constant_memory": (len(mem_marks) < 2) or (mem_marks[-1] <= mem_marks[0]),
+                    "peak_mem_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                    "kernel_ms_in_one_call": kern3}
+        del xb, cache3
 
-    # ---- configs[1] leg (rank 0, N=1; reported beside the headline, never mixed into `value`): one 4096-token
-    #      prefill call on a fresh cache (chunk path over 64 chunks; SWA purely causal) + 128 graphed decode steps
+    # ---- configs[1] leg (EVERY rank: one sequence per GPU; reported beside the headline, never mixed into `value`): one
+    #      4096-token prefill call on a fresh cache (chunk path over 64 chunks; SWA purely causal) + 128 graphed decode steps;
+    #      the slowest rank defines both times (MAX over ranks), aggregates are all ranks' tokens over them
     cfg1 = None
-    if rank == 0 and world == 1 and not args.no_cfg1:
+    if not args.no_cfg1:
         del step, dec
         Tp, reps = 4096, 3
-        ids = torch.randint(0, cfg.vocab_size, (1, Tp), device=device,
-                            generator=torch.Generator(device=device).manual_seed(1))
-        pid = torch.arange(Tp, device=device)[None, None, :].expand(3, 1, Tp).contiguous()
-        cache1 = model.allocate_inference_cache(1)
-        times = []
-        with torch.no_grad():
-            for r in range(reps + 1):
-                cache1.reset()
-                torch.cuda.synchronize()
-                tA = time.perf_counter()
-                _, lg = model(input_ids=ids, position_ids=pid, past_key_values=cache1, logits_to_keep=1)
-                torch.cuda.synchronize()
-                if r > 0:
-                    times.append(time.perf_counter() - tA)
-        dec1 = GraphedDecode(model, cache1, 1)
-        dec1.token.copy_(lg[:, -1].argmax(-1, keepdim=True))
-        dec1.capture()
-        for _ in range(4):
-            dec1.step()
-        torch.cuda.synchronize()
-        tA = time.perf_counter()
-        for _ in range(128):
-            dec1.step()
-        torch.cuda.synchronize()
-        tdec = time.perf_counter() - tA
-        pf = min(times)
-        cfg1 = {"workload": "configs[1]: 4096-token prefill in one call (eager launches) + 128 graphed decode steps, B=1",
-                "prefill_ms": pf * 1e3, "prefill_tok_s": Tp / pf, "decode_tok_s": 128 / tdec,
-                "decode_ms_per_token": tdec / 128 * 1e3, "logits_finite": bool(torch.isfinite(lg.float()).all())}
-        del dec1, cache1
+        err1, pf, tdec, fin1 = None, None, None, None
+        try:
+            ids = torch.randint(0, cfg.vocab_size, (1, Tp), device=device,
+                                generator=torch.Generator(device=device).manual_seed(1 + rank))
+            pid = torch.arange(Tp, device=device)[None, None, :].expand(3, 1, Tp).contiguous()
+            cache1 = model.allocate_inference_cache(1)
+            times = []
+            with torch.no_grad():
+                for r in range(reps + 1):
+                    cache1.reset()
+                    torch.cuda.synchronize()
+                    tA = time.perf_counter()
+                    _, lg = model(input_ids=ids, position_ids=pid, past_key_values=cache1, logits_to_keep=1)
+                    torch.cuda.synchronize()
+                    if r > 0:
+                        times.append(time.perf_counter() - tA)
+            dec1 = GraphedDecode(model, cache1, 1)
+            dec1.token.copy_(lg[:, -1].argmax(-1, keepdim=True))
+            dec1.capture()
+            for _ in range(4):
+                dec1.step()
+            torch.cuda.synchronize()
+            tA = time.perf_counter()
+            for _ in range(128):
+                dec1.step()
+            torch.cuda.synchronize()
+            tdec = time.perf_counter() - tA
+            pf = min(times)
+            fin1 = bool(torch.isfinite(lg.float()).all())
+            del dec1, cache1
+        except Exception as e:               # noqa: BLE001
+            err1 = f"{type(e).__name__}: {e}"
+        if not all_ok(err1 is None):
+            cfg1 = {"error": err1 or "failed on another rank", "failed": True}
+        else:
+            pf, tdec = ivd.max_over_ranks(pf, device), ivd.max_over_ranks(tdec, device)
+            fin1 = all_ok(fin1)
+            cfg1 = {"workload": f"configs[1]: 4096-token prefill in one call (eager launches) + 128 graphed decode steps, B=1 per GPU, "
+                                f"{world} GPU(s) (batch-sharded; slowest rank's times)",
+                    "n_gpus": world, "prefill_ms": pf * 1e3, "prefill_tok_s": world * Tp / pf, "decode_tok_s": world * 128 / tdec,
+                    "decode_ms_per_token": tdec / 128 * 1e3, "logits_finite": fin1}
 
     kernels, cpu = None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = kernel_timings(device, T, args.window, live_prefill=live_prefill, live_decode=live_decode)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:          # rank 0 at any N (the other ranks wait in the barrier below)
         cpu = cpu_baseline(T, args.window)
     ivd.barrier()
 

@@ -1724,7 +1724,7 @@ def test_bench_two_ranks_reports_what_the_collective_ran_on():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--layers", "4", "--context", "8192", "--decode-steps", "2", "--no-cpu-baseline", "--no-cfg1", "--no-cfg3",
+                        "--layers", "4", "--context", "8192", "--decode-steps", "2",
                         "--no-fp8", "--no-kernel-timing", "--sp-tokens", "1024"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -1743,6 +1743,20 @@ def test_bench_two_ranks_reports_what_the_collective_ran_on():
     assert sp["last_token_logits_equal_single_rank_run"] is True and sp["max_abs_diff"] == 0.0 and sp["logits_finite"]
     assert sp["ms"] > 0 and sp["tok_s"] > 0 and sp["single_rank_ms_same_calls"] > 0 and sp["failed"] is False
     assert out["logits_finite"] and out["value"] > 0
+    # at N > 1 the line is COMPLETE -- the configs[3] leg runs on EVERY rank (one sequence per GPU = "batch
+    # sharded"), with one record per rank, the slowest rank's barrier-to-barrier time, the aggregate over all ranks and the one
+    # logits gather; the configs[1] leg likewise; cpu_baseline stays on rank 0
+    c3 = out["cfg3_512k_prefill"]
+    assert c3.get("failed") is not True, c3
+    assert c3["n_gpus"] == 2 and c3["sequences"] == 2 and len(c3["per_rank_ms"]) == 2 and all(v > 0 for v in c3["per_rank_ms"])
+    assert c3["tokens_timed_all_ranks"] == 2 * c3["calls_timed"] * 4096 and c3["ms_per_call"] == max(c3["per_rank_ms"])
+    assert abs(c3["aggregate_tok_s"] - c3["tokens_timed_all_ranks"] / (c3["region_ms_max_over_ranks"] * 1e-3)) < 1e-3 * c3["aggregate_tok_s"]
+    assert c3["region_ms_max_over_ranks"] >= c3["calls_timed"] * min(c3["per_rank_ms"]) * 0.99
+    assert c3["gathered_logits_shape"] == [2, 151936] and c3["gather_ms"] > 0 and c3["logits_finite"] and c3["constant_memory"]
+    c1 = out["cfg1_4k_prefill_decode"]
+    assert c1["n_gpus"] == 2 and c1["prefill_tok_s"] > 0 and c1["decode_tok_s"] > 0 and c1["logits_finite"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle/model.py" in cb["sample"]
 
 
 def test_full_attention_layer_with_dynamic_cache_equals_one_causal_call():
