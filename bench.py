@@ -396,6 +396,12 @@ def kernel_timings(device, chunk, window, only=None, live_prefill=None, live_dec
     add("swa_prefill@T=4096(full ring, rope + append)", lambda i: ops.swa_forward(
         *qkvL, window=window, scaling=d ** -0.5, k_cache=rings[0][0], v_cache=rings[0][1], pos_dev=pos_dev,
         rope=(cosL, sinL, (16, 24, 24)), append=True), 5, "other", 0, "mfma", 4.0 * Hq * d * window * TL)
+    # the same call on the 256-row kernel (swa_ring256.hip: linearize pre-pass with the append + attention on the linear keys) --
+    # what cache.attend selects outside a capture once the ring is full; the entry above stays on the 128-row kernel
+    add("swa_ring256@T=4096(full ring, rope + append)", lambda i: ops.swa_forward(
+        *qkvL, window=window, scaling=d ** -0.5, k_cache=rings[0][0], v_cache=rings[0][1], pos_dev=pos_dev,
+        rope=(cosL, sinL, (16, 24, 24)), append=True, pos_min=10 * window, pos_min_holds_in_graph=True),
+        5, "other", 0, "mfma", 4.0 * Hq * d * window * TL)
     del ginL, projL, qkvL
     # vision tower (not part of the text-stack step): 8 frames of 32 x 32 patches, 16 heads x 80,
     # rotary embedding folded in; a window layer (64-patch segments) and a full-attention layer (one segment per frame).

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IVL_ABI_VERSION 10
+#define IVL_ABI_VERSION 11
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define IVL_API __attribute__((visibility("default")))
@@ -241,9 +241,18 @@ typedef struct ivl_swa_args {
   int append_new;           /* != 0: after the attention, also append the call's T tokens to the ring (what ivl_swa_cache_append
                                does, same rope arguments) - inside the split-KV combine launch when there is one, so that a
                                layer costs one launch less.  Needs a ring cache and T_new == T.                      */
+  int64_t pos_min;          /* a lower bound of the position the CALLER guarantees (0: none).  The position itself may live in
+                               device memory (pos_dev), but a long call over a FULL ring (pos_min >= cache_capacity, window ==
+                               cache_capacity + 1, T a multiple of 256, >= 256 workgroups of 256 rows, workspace of
+                               ivl_swa_ring256_workspace_bytes) takes the 256-row form: the pre-pass lays the ring out in
+                               chronological order in front of the call's keys (and appends), the attention kernel has no
+                               ring / band arithmetic in its steady state.  Never set it for a call recorded into a graph that
+                               may be replayed from an earlier position.                                                  */
 } ivl_swa_args;
 
 IVL_API size_t ivl_swa_workspace_bytes(int B, int T, int Hq, int d);
+/* Workspace of the 256-row form of a long call over a full ring (see ivl_swa_args.pos_min); 0: the shape does not qualify. */
+IVL_API size_t ivl_swa_ring256_workspace_bytes(int B, int T, int Hq, int Hkv, int d, int cache_capacity);
 IVL_API int ivl_swa_fwd(const ivl_swa_args* args, void* stream);
 
 /* Append the T new tokens to the ring (slot (pos+t) % C) -- after ivl_swa_fwd of the same call.

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ivl_vision_attn_workspace_bytes", "ivl_vision_attn_fwd", "ivl_norm_linear_small_m_fwd",
     "ivl_gdn_sync_status", "ivl_gdn_sync_reset", "ivl_gdn_resident_blocks",
     "ivl_short_conv_bias_fwd", "ivl_rmsnorm_swish_gate_res_fwd", "ivl_gdn_recurrent_f16_fwd",
-    "ivl_gdn_decode_split_fwd", "ivl_gdn_out_linear_small_m_fwd",
+    "ivl_gdn_decode_split_fwd", "ivl_gdn_out_linear_small_m_fwd", "ivl_swa_ring256_workspace_bytes",
 )
 
 
@@ -47,6 +47,7 @@ class SwaArgs(Structure):
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_s0", c_int), ("rope_s1", c_int),
         ("mma_dtype", c_int), ("append_new", c_int),
+        ("pos_min", c_int64),
     ]
 
 
@@ -115,6 +116,8 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.ivl_mrope_fwd.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
     lib.ivl_swa_workspace_bytes.restype = sz
     lib.ivl_swa_workspace_bytes.argtypes = [i, i, i, i]
+    lib.ivl_swa_ring256_workspace_bytes.restype = sz
+    lib.ivl_swa_ring256_workspace_bytes.argtypes = [i, i, i, i, i, i]
     lib.ivl_swa_fwd.restype = i
     lib.ivl_swa_fwd.argtypes = [POINTER(SwaArgs), vp]
     lib.ivl_swa_cache_append.restype = i

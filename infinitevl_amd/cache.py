@@ -117,7 +117,7 @@ class StaticSlidingWindowLayerPrealloc(_HFLayer):
         # attention over (ring ++ new), then the append: one call (the append rides in the split-KV combine launch)
         o = ops.swa_forward(q, k_new, v_new, window=window, scaling=scaling,
                             k_cache=self._buf_keys, v_cache=self._buf_values, pos_dev=self._pos_dev, mma_dtype=mma_dtype,
-                            rope=rope, append=self.capacity > 0)
+                            rope=rope, append=self.capacity > 0, pos_min=self.cumulative_length)
         if self._advances_counter:
             ops.counter_add(self._pos_dev, T)
         self.advance(T)

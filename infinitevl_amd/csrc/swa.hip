@@ -13,14 +13,11 @@
 //   lo = max(0, n_prev + t - W + 1) .. hi = n_prev + t.
 // Long key ranges are optionally split across workgroups (flash-decoding); a combine kernel merges.
 #include "ivl_common.h"
+#include "swa_shared.h"
 #include <type_traits>
 
 namespace ivl {
 
-typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int SWA_D = 128;
 constexpr int SWA_QT = 64;           // query rows per workgroup
 constexpr int SWA_KT = 64;           // keys per tile
 constexpr int SWA_KSTRIDE = 256;     // bytes per K row in LDS; 16-byte pieces XOR-swizzled by the row (see below)
@@ -29,7 +26,6 @@ constexpr int SWA_LDS_K = SWA_KT * SWA_KSTRIDE;
 constexpr int SWA_LDS_BYTES = SWA_LDS_K + SWA_KT * SWA_VSTRIDE;
 constexpr int SWA_MAX_SPLIT = 16;        // prefill / split-KV with register-resident combine
 constexpr int SWA_MAX_SPLIT_PACK = 64;   // packed decode rows: one 64-key tile per workgroup
-constexpr float LOG2E = 1.4426950408889634f;
 IVL_TRACE_DECL(swa)
 
 struct SwaParams {
@@ -45,34 +41,9 @@ struct SwaParams {
   const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
 };
 
-// x mod C for a token position x >= 0 and a ring capacity C > 0: every workgroup computes the ring slot of its first key
-// from the device-resident position before it can request a tile, and a 64-bit remainder by a run-time divisor is ~150
-// instructions; positions below 2^32 (4 G tokens: the usual case, wave-uniform branch) take the 32-bit expansion.
-__device__ __forceinline__ int mod_pos(long long x, int C) {
-  if ((unsigned long long)x < 0x100000000ull) return (int)((unsigned int)x % (unsigned int)C);
-  return (int)(x % C);
-}
-
-__device__ __forceinline__ mfma_bf16x8 as_mfma(u32x4 v) {
-  mfma_bf16x8 r;
-  __builtin_memcpy(&r, &v, 16);
-  return r;
-}
-
 // QG = 16-row query groups per wave (1: 64 rows per workgroup, decode / short calls; 2: 128 rows per workgroup).
 // With QG = 2 every K / V^T fragment read from LDS feeds two MFMAs: at QG = 1 the 4 waves of a workgroup pull
 // 128 KB through the 128 B/clk LDS port per 64-key tile (1024 clk) for 512 clk of MFMA work per SIMD.
-// single-instruction max helpers (a plain fmaxf on MFMA results draws a canonicalising v_max per operand)
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float vmax2(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 // butterfly over the four 16-lane groups of a wave (the lanes that share a query row) on the gfx950 lane-swap
 // instructions: v_permlane16_swap exchanges odd rows of one operand with even rows of the other, v_permlane32_swap
 // the upper half with the lower half; with both operands = x the two results hold x and its partner.
@@ -87,45 +58,6 @@ __device__ __forceinline__ float group_sum(float x) {
   x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
-// M-RoPE (std:949-984) on one pair of 8-channel groups of one row: channels c0..c0+7 ("lo") and c0+64..c0+71 ("hi").
-// cos/sin: [3, B, T, 128] bf16 tables (t, h, w); the channel block selects its table by the mrope sections (s0 | s1 | rest,
-// multiples of 8).  Products and the sum are each rounded to bf16 like the reference's eager bf16 arithmetic: bit-identical
-// to ivl_mrope_fwd.  `row_off` = (b * T + t) * 128, `plane` = B * T * 128.
-// the arithmetic of rope_pair on tables already in registers
-__device__ __forceinline__ void rope_apply(u32x4& lo, u32x4& hi, const u32x4 c1, const u32x4 n1, const u32x4 c2, const u32x4 n2) {
-  const unsigned int x1[4] = {lo.x, lo.y, lo.z, lo.w}, x2[4] = {hi.x, hi.y, hi.z, hi.w};
-  const unsigned int cc1[4] = {c1.x, c1.y, c1.z, c1.w}, nn1[4] = {n1.x, n1.y, n1.z, n1.w};
-  const unsigned int cc2[4] = {c2.x, c2.y, c2.z, c2.w}, nn2[4] = {n2.x, n2.y, n2.z, n2.w};
-  unsigned int o1[4], o2[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a0 = bflo(x1[i]), a1 = bfhi(x1[i]), b0 = bflo(x2[i]), b1 = bfhi(x2[i]);
-    o1[i] = pack2bf(bf_round(a0 * bflo(cc1[i])) + bf_round(-b0 * bflo(nn1[i])), bf_round(a1 * bfhi(cc1[i])) + bf_round(-b1 * bfhi(nn1[i])));
-    o2[i] = pack2bf(bf_round(b0 * bflo(cc2[i])) + bf_round(a0 * bflo(nn2[i])), bf_round(b1 * bfhi(cc2[i])) + bf_round(a1 * bfhi(nn2[i])));
-  }
-  lo = u32x4{o1[0], o1[1], o1[2], o1[3]};
-  hi = u32x4{o2[0], o2[1], o2[2], o2[3]};
-}
-__device__ __forceinline__ void rope_pair(u32x4& lo, u32x4& hi, const bf16_t* cosp, const bf16_t* sinp, long long plane,
-                                          long long row_off, int c0, int s0, int s1) {
-  const int sec = c0 < s0 ? 0 : (c0 < s0 + s1 ? 1 : 2);
-  const long long off = sec * plane + row_off + c0;
-  const u32x4 c1 = *(const u32x4*)(cosp + off), n1 = *(const u32x4*)(sinp + off);
-  const u32x4 c2 = *(const u32x4*)(cosp + off + 64), n2 = *(const u32x4*)(sinp + off + 64);
-  const unsigned int x1[4] = {lo.x, lo.y, lo.z, lo.w}, x2[4] = {hi.x, hi.y, hi.z, hi.w};
-  const unsigned int cc1[4] = {c1.x, c1.y, c1.z, c1.w}, nn1[4] = {n1.x, n1.y, n1.z, n1.w};
-  const unsigned int cc2[4] = {c2.x, c2.y, c2.z, c2.w}, nn2[4] = {n2.x, n2.y, n2.z, n2.w};
-  unsigned int o1[4], o2[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a0 = bflo(x1[i]), a1 = bfhi(x1[i]), b0 = bflo(x2[i]), b1 = bfhi(x2[i]);
-    o1[i] = pack2bf(bf_round(a0 * bflo(cc1[i])) + bf_round(-b0 * bflo(nn1[i])), bf_round(a1 * bfhi(cc1[i])) + bf_round(-b1 * bfhi(nn1[i])));
-    o2[i] = pack2bf(bf_round(b0 * bflo(cc2[i])) + bf_round(a0 * bflo(nn2[i])), bf_round(b1 * bfhi(cc2[i])) + bf_round(a1 * bfhi(nn2[i])));
-  }
-  lo = u32x4{o1[0], o1[1], o1[2], o1[3]};
-  hi = u32x4{o2[0], o2[1], o2[2], o2[3]};
 }
 
 template <bool PACK, int QG>
@@ -1334,6 +1266,8 @@ static int swa_base_nsplit(int B, int T, int Hq) {
   return (int)ns;
 }
 
+int swa_ring256_launch(const ivl_swa_args* a, hipStream_t st);      // swa_ring256.hip
+
 }  // namespace ivl
 
 using namespace ivl;
@@ -1374,6 +1308,12 @@ extern "C" int ivl_swa_fwd(const ivl_swa_args* a, void* stream) {
   IVL_REQUIRE((long long)a->T_new * a->kn_st < (1LL << 32) && a->kn_st >= 0, IVL_ERR_UNSUPPORTED,
               "ivl_swa_fwd: T_new * kn_st = %lld elements exceeds the 32-bit row addressing of the kernel (split the call)",
               (long long)a->T_new * a->kn_st);
+  // a long call over a FULL ring (the caller vouches for pos >= C): the 256-row form on a linear copy of the keys (swa_ring256.hip)
+  if (a->pos_min >= a->cache_capacity && a->cache_capacity > 0 && a->window == a->cache_capacity + 1 && a->T_new == a->T &&
+      a->mma_dtype == IVL_BF16 && a->pos_min >= 0 && (a->pos_dev != nullptr || a->pos >= a->cache_capacity)) {
+    const size_t need = ivl_swa_ring256_workspace_bytes(a->B, a->T, a->Hq, a->Hkv, a->d, a->cache_capacity);
+    if (need != 0 && a->workspace != nullptr && a->workspace_bytes >= need) return swa_ring256_launch(a, (hipStream_t)stream);
+  }
   const int G = a->Hq / a->Hkv;
   const bool pack = (long long)a->T * G <= SWA_QT && G <= 16;
   // worst-case number of key tiles a workgroup walks (n_prev unknown under graph replay -> capacity)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 import threading
 import weakref
 from typing import Dict, Optional, Tuple
@@ -964,11 +965,15 @@ def apply_mrope_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin
     return q, k
 
 
+# the 256-row kernel for long calls over a full ring (swa_ring256.hip); IVL_SWA_RING256=0 keeps every call on the 128-row kernel
+SWA_RING256 = os.environ.get("IVL_SWA_RING256", "1") != "0"
+
+
 def swa_forward(
     q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, *, window: Optional[int], scaling: float,
     k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
     pos: int = 0, pos_dev: Optional[torch.Tensor] = None, n_query: Optional[int] = None,
-    layout: str = "bthd", mma_dtype=None, rope=None, append: bool = False,
+    layout: str = "bthd", mma_dtype=None, rope=None, append: bool = False, pos_min: int = 0, pos_min_holds_in_graph: bool = False,
 ) -> torch.Tensor:
     """Sliding-window GQA attention over (ring cache ++ new keys); returns o [B,T,Hq,d] bf16.
 
@@ -978,7 +983,11 @@ def swa_forward(
     `rope=(cos, sin, mrope_section)` (cos/sin bf16 [3,B,T,d]): q and k_new are the UN-rotated projections and M-RoPE
     (std:949-984) is applied while they are loaded -- bit-identical to apply_mrope_inplace followed by this call.
     `append=True`: the call's tokens are also appended to the ring afterwards (swa_cache_append's work, folded into the
-    split-KV combine launch when there is one)."""
+    split-KV combine launch when there is one).
+    `pos_min`: a lower bound of the position the caller vouches for (the host-side counter of the cache) when the position
+    itself is read from `pos_dev`: a long call over a FULL ring (pos_min >= C) takes the 256-row kernel on a linear copy of the
+    keys (ivl_swa_args.pos_min).  Ignored while a stream capture is recording (a replay may start from an earlier position)
+    unless `pos_min_holds_in_graph` says the bound holds for every replay (the kernel micro-benchmarks replay one position)."""
     _need_gpu(q, k_new, v_new, k_cache, v_cache, pos_dev)
     if q.dtype != torch.bfloat16 or k_new.dtype != torch.bfloat16 or v_new.dtype != torch.bfloat16:
         raise ValueError("swa_forward is built for bf16")
@@ -1000,6 +1009,12 @@ def swa_forward(
     o = torch.empty(B, T, Hq, d, dtype=torch.bfloat16, device=q.device)
     lib = _lib.load()
     nbytes = lib.ivl_swa_workspace_bytes(B, T, Hq, d)
+    pos_min = int(pos_min) if pos_dev is not None else int(pos)
+    if not (SWA_RING256 and C > 0 and pos_min >= C and T >= 256 and T_new == T and window == C + 1) or (
+            torch.cuda.is_current_stream_capturing() and not pos_min_holds_in_graph):
+        pos_min = 0
+    else:
+        nbytes = max(nbytes, lib.ivl_swa_ring256_workspace_bytes(B, T, Hq, Hkv, d, C))
     ws = get_workspace(nbytes, q.device, "swa")
     a = SwaArgs()
     a.q, a.k_new, a.v_new, a.k_cache, a.v_cache, a.o = (q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
@@ -1016,6 +1031,7 @@ def swa_forward(
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     a.mma_dtype = mma_code(mma_dtype)
     a.append_new = int(bool(append) and C > 0)
+    a.pos_min = pos_min
     if rope is not None:
         cos, sin, sec = _rope_args(rope, B, T, d)
         a.rope_cos, a.rope_sin, a.rope_s0, a.rope_s1 = cos.data_ptr(), sin.data_ptr(), int(sec[0]), int(sec[1])

@@ -44,7 +44,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ivl_abi_version() == 10
+    assert lib.ivl_abi_version() == 11
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():

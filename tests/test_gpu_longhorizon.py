@@ -143,10 +143,10 @@ def test_stream_32k_tokens_graphed_step_vs_oracle_8_ring_revolutions():
 def test_stream_131k_tokens_headline_geometry_vs_oracle():
     """The headline workload's own geometry (configs[2]: 512 x 256 tokens = 131,072, W = 4096, hipGraph step) on the
     small-heads stack, against the oracle over the WHOLE length: 32 revolutions of the 4095-slot ring, 512 bf16 state
-    roundings.  (The exact-fp32 third run is left to the 32K-token test: here `model` columns stand in for `exact`.)"""
+    roundings."""
     n, T, W = 512, 256, 4096
-    at, per_step = _stream_stack(n, T, W, checkpoints={1, 16, 17, 64, 128, 256, 512}, exact=False)
-    _check_stream(at, per_step, n, T, W, h_bound=1.5e-2, exact=False)
+    at, per_step = _stream_stack(n, T, W, checkpoints={1, 16, 17, 64, 128, 256, 512})
+    _check_stream(at, per_step, n, T, W, h_bound=1.5e-2)
 
 
 def _decay_mix(seed: int, T: int, H: int):

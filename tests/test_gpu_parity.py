@@ -1749,7 +1749,7 @@ def test_bench_two_ranks_reports_what_the_collective_ran_on():
     c3 = out["cfg3_512k_prefill"]
     assert c3.get("failed") is not True, c3
     assert c3["n_gpus"] == 2 and c3["sequences"] == 2 and len(c3["per_rank_ms"]) == 2 and all(v > 0 for v in c3["per_rank_ms"])
-    assert c3["tokens_timed_all_ranks"] == 2 * c3["calls_timed"] * 4096 and c3["ms_per_call"] == max(c3["per_rank_ms"])
+    assert c3["tokens_timed_all_ranks"] == 2 * c3["calls_timed"] * 4096 and abs(c3["ms_per_call"] - max(c3["per_rank_ms"])) < 1e-3
     assert abs(c3["aggregate_tok_s"] - c3["tokens_timed_all_ranks"] / (c3["region_ms_max_over_ranks"] * 1e-3)) < 1e-3 * c3["aggregate_tok_s"]
     assert c3["region_ms_max_over_ranks"] >= c3["calls_timed"] * min(c3["per_rank_ms"]) * 0.99
     assert c3["gathered_logits_shape"] == [2, 151936] and c3["gather_ms"] > 0 and c3["logits_finite"] and c3["constant_memory"]

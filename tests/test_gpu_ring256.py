@@ -1,0 +1,154 @@
+"""GPU (-m gpu): the 256-row attention path of long calls over a FULL ring (csrc/swa_ring256.hip: linearize pre-pass with the ring
+append folded in + attention on the linear copy of the keys) against
+  (a) the CPU oracle (oracle.swa.swa_attention: softmax attention on the S2 band, fp32) -- RMS-relative <= 5e-3, the tolerance of the
+      text-stack attention tests;
+  (b) the 128-row product kernel on the same call (pos_min = 0 keeps a call there): outputs within 2 x 5e-3 of each other (two bf16
+      results of one operator), and the RING after the call BIT-EQUAL (the fold of the append must place exactly the same rotated
+      keys in exactly the same slots), for ring histories that wrap, T > C, T == C + 1, odd capacities;
+  (c) itself across calls: N consecutive long calls == the same calls on the 128-row kernel, ring and outputs."""
+import pytest
+import torch
+
+from conftest import rms_rel
+from oracle import swa as oswa
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import infinitevl_amd
+    infinitevl_amd.load_library()
+    yield
+
+
+def _inputs(B, T, Hq, Hkv, seen, seed, d=128):
+    g_ = torch.Generator().manual_seed(seed)
+    bf = lambda x: x.to(torch.bfloat16)  # noqa: E731
+    q = bf(torch.randn(B, T, Hq, d, generator=g_))
+    k_all = bf(torch.randn(B, seen + T, Hkv, d, generator=g_))
+    v_all = bf(torch.randn(B, seen + T, Hkv, d, generator=g_))
+    return q, k_all, v_all
+
+
+def _filled_ring(k_all, v_all, seen, W, dev=DEV):
+    """Ring after `seen` tokens, fed in irregular pieces (wrap-around), position counter on the device."""
+    from infinitevl_amd import ops
+    B, _, Hkv, d = k_all.shape
+    C = W - 1
+    kc = torch.zeros(B, Hkv, C, d, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    pos_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    kd, vd = k_all.to(dev), v_all.to(dev)
+    pos, step = 0, 301
+    while pos < seen:
+        n = min(step, seen - pos, C)
+        ops.swa_cache_append(kd[:, pos:pos + n], vd[:, pos:pos + n], kc, vc, pos_dev=pos_dev)
+        ops.counter_add(pos_dev, n)
+        pos += n
+        step = step * 2 + 1
+    return kc, vc, pos_dev
+
+
+def _rope_tables(B, T, first, dev=DEV):
+    from infinitevl_amd import ops
+    pid = torch.arange(first, first + T, device=dev)[None, None, :].expand(3, B, T).contiguous()
+    pid = pid + torch.tensor([0, 3, 11], device=dev)[:, None, None]            # three different axes
+    inv_freq = 1.0 / (1e6 ** (torch.arange(0, 128, 2, device=dev, dtype=torch.float32) / 128))
+    return ops.rope_tables(pid, inv_freq, 1.0)
+
+
+@pytest.mark.parametrize("B,T,W,seen", [(4, 1024, 1024, 1500), (8, 512, 512, 511), (4, 1024, 1000, 5000), (2, 2048, 700, 699),
+                                       (1, 4096, 4096, 4095)])
+def test_ring256_vs_oracle_and_ring_bit_equal_to_128_row_path(B, T, W, seen):
+    """No rope (the operator on rotated inputs): the 256-row path within 5e-3 of the oracle on every row; ring afterwards bit-equal
+    to the 128-row path's; capacities 1023 / 511 / 999 / 699 / 4095 (different numbers of masked edge tiles, T > C, T == C + 1)."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d = 16, 2, 128
+    C = W - 1
+    assert ops._lib.load().ivl_swa_ring256_workspace_bytes(B, T, Hq, Hkv, d, C) > 0
+    q, k_all, v_all = _inputs(B, T, Hq, Hkv, seen, seed=B * 1000 + T + W)
+    outs, rings = [], []
+    for pm in (seen, 0):
+        kc, vc, pos_dev = _filled_ring(k_all, v_all, seen, W)
+        o = ops.swa_forward(q.to(DEV), k_all[:, seen:].to(DEV), v_all[:, seen:].to(DEV), window=W, scaling=d ** -0.5, k_cache=kc,
+                            v_cache=vc, pos_dev=pos_dev, append=True, pos_min=pm)
+        torch.cuda.synchronize()
+        outs.append(o.float().cpu())
+        rings.append((kc.clone(), vc.clone()))
+    assert torch.equal(rings[0][0], rings[1][0]) and torch.equal(rings[0][1], rings[1][1])
+    n_prev = min(C, seen)
+    # oracle on whole heads for the small shapes, on two heads x three 64-row slabs for the 4096-token one
+    if T <= 2048:
+        ref = oswa.swa_attention(q.float().transpose(1, 2), k_all[:, seen - n_prev:].float().transpose(1, 2),
+                                 v_all[:, seen - n_prev:].float().transpose(1, 2), n_prev, W, d ** -0.5)
+        e_new, e_old = rms_rel(ref, outs[0]), rms_rel(ref, outs[1])
+    else:
+        errs_new, errs_old = [], []
+        for h in (0, 15):
+            for t0 in (0, 1984, T - 64):
+                hk = h // (Hq // Hkv)
+                ref = oswa.swa_attention(q[:, t0:t0 + 64, h:h + 1].float().transpose(1, 2),
+                                         k_all[:, seen - n_prev:seen + t0 + 64, hk:hk + 1].float().transpose(1, 2),
+                                         v_all[:, seen - n_prev:seen + t0 + 64, hk:hk + 1].float().transpose(1, 2), n_prev + t0, W, d ** -0.5)
+                errs_new.append(rms_rel(ref, outs[0][:, t0:t0 + 64, h:h + 1]))
+                errs_old.append(rms_rel(ref, outs[1][:, t0:t0 + 64, h:h + 1]))
+        e_new, e_old = max(errs_new), max(errs_old)
+    e_pair = rms_rel(outs[1], outs[0])
+    print(f"ring256 B={B} T={T} W={W} seen={seen}: vs oracle {e_new:.2e} (128-row path {e_old:.2e}), between the paths {e_pair:.2e}")
+    assert torch.isfinite(outs[0]).all()
+    assert e_new < 5e-3 and e_old < 5e-3 and e_pair < 1e-2, (e_new, e_old, e_pair)
+
+
+@pytest.mark.parametrize("B,T,W,seen", [(1, 4096, 4096, 9000), (4, 1024, 1024, 1023)])
+def test_ring256_with_fused_rope_three_consecutive_calls(B, T, W, seen):
+    """The product form (un-rotated q / k + M-RoPE tables, append folded into the pre-pass), three consecutive long calls on one
+    ring against the same three calls on the 128-row kernel: ring bit-equal after every call, outputs within 1e-2, position
+    untouched by either."""
+    from infinitevl_amd import ops
+    Hq, Hkv, d = 16, 2, 128
+    q, k_all, v_all = _inputs(B, 3 * T, Hq, Hkv, seen, seed=7)
+    state = {}
+    for name, pm_on in (("new", True), ("old", False)):
+        kc, vc, pos_dev = _filled_ring(k_all, v_all, seen, W)
+        outs, ring_snap = [], []
+        for c in range(3):
+            a = seen + c * T
+            cos, sin = _rope_tables(B, T, a)
+            o = ops.swa_forward(q[:, c * T:(c + 1) * T].to(DEV), k_all[:, a:a + T].to(DEV), v_all[:, a:a + T].to(DEV), window=W,
+                                scaling=d ** -0.5, k_cache=kc, v_cache=vc, pos_dev=pos_dev, rope=(cos, sin, (16, 24, 24)), append=True,
+                                pos_min=a if pm_on else 0)
+            assert int(pos_dev.item()) == a
+            ops.counter_add(pos_dev, T)
+            outs.append(o.float().cpu())
+            ring_snap.append((kc.clone(), vc.clone()))
+        state[name] = (outs, ring_snap)
+    for c in range(3):
+        assert torch.equal(state["new"][1][c][0], state["old"][1][c][0]), c
+        assert torch.equal(state["new"][1][c][1], state["old"][1][c][1]), c
+        e = rms_rel(state["old"][0][c], state["new"][0][c])
+        print(f"ring256 + rope, call {c}: between the paths {e:.2e}")
+        assert torch.isfinite(state["new"][0][c]).all() and e < 1e-2, (c, e)
+
+
+def test_ring256_is_not_taken_without_the_callers_bound_or_under_capture():
+    """pos_min = 0 (default) and a recording capture keep the call on the 128-row kernel: the launcher must not read the ring as full
+    on its own.  Checked by the launch names of a profiled call."""
+    from torch.profiler import ProfilerActivity, profile
+    from infinitevl_amd import ops
+    B, T, W, seen, Hq, Hkv, d = 4, 1024, 1024, 2000, 16, 2, 128
+    q, k_all, v_all = _inputs(B, T, Hq, Hkv, seen, seed=3)
+    kc, vc, pos_dev = _filled_ring(k_all, v_all, seen, W)
+    args = (q.to(DEV), k_all[:, seen:].to(DEV), v_all[:, seen:].to(DEV))
+
+    def names(**kw):
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            ops.swa_forward(*args, window=W, scaling=d ** -0.5, k_cache=kc, v_cache=vc, pos_dev=pos_dev, **kw)
+            torch.cuda.synchronize()
+        return [e.name for e in prof.events() if "ivl::" in e.name]
+    assert any("swa_ring256_kernel" in n for n in names(pos_min=seen))
+    assert not any("ring256" in n or "linearize" in n for n in names())
+    assert not any("ring256" in n or "linearize" in n for n in names(pos_min=W - 2))      # a bound below the capacity is no bound
