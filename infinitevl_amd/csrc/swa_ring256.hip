@@ -5,7 +5,7 @@
 // Everything else stays on swa_prefill_kernel / swa_fwd_kernel (swa.hip).
 //
 // Two launches:
-//  (1) swa_linearize_kernel -- the rope pre-pass of the long calls, extended: rotated q -> q_rot; the ring in CHRONOLOGICAL order
+//  (1) swa_linearize_kernel -- the rope pre-pass of the long calls, re-cut: the ring in CHRONOLOGICAL order
 //      followed by the call's rotated keys / values -> k_lin / v_lin [B, Hkv, C + T + 64, 128] (64 zero rows behind); and the ring
 //      append itself (the thread that moves ring slot s out writes the call's token that lands in s: no reader of the old slot is
 //      left, the attention kernel below reads the linear copy only).  With the keys linear in memory the attention kernel has NO
@@ -30,6 +30,9 @@ constexpr int R2_STAGE = 2 * R2_KT * 256;    // K image + V image = 32 KB
 constexpr int R2_NST = 4;                    // stages
 constexpr int R2_AHEAD = 3;                  // tiles requested ahead
 constexpr int R2_LDS = R2_NST * R2_STAGE;    // 128 KB
+#ifndef R2_DMA_AT
+#define R2_DMA_AT 0                          // where the four DMA pieces of a tile are issued: 0 behind the row maximum, 1 behind the
+#endif                                       // exponentials, 2 two and two
 constexpr int R2_PAD_ROWS = 64;              // zero rows behind the linear keys (the last tile of the last q-tile ends 1 key late)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -43,11 +46,11 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
 }
 
 struct LinArgs {
-  const bf16_t* q; long long q_sb, q_st, q_sh;
+  const bf16_t* q; long long q_sb, q_st, q_sh; bf16_t* q_rot; int Hq;      // q_rot == NULL: the attention kernel rotates q itself
   const bf16_t* k_new; const bf16_t* v_new; long long kn_sb, kn_st, kn_sh;
   bf16_t* k_cache; bf16_t* v_cache;
-  bf16_t* q_rot; bf16_t* k_lin; bf16_t* v_lin;
-  int B, T, Hq, Hkv, C; long long pos; const long long* pos_dev;
+  bf16_t* k_lin; bf16_t* v_lin;
+  int B, T, Hkv, C; long long pos; const long long* pos_dev;
   const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
   int append;
 };
@@ -57,24 +60,13 @@ __global__ __launch_bounds__(256) void swa_linearize_kernel(LinArgs a) {
   const long long pos = a.pos_dev ? *a.pos_dev : a.pos;
   const int pos_slot = mod_pos(pos, a.C);
   const long long Lp = (long long)a.C + a.T + R2_PAD_ROWS;
-  const long long nQ = (long long)a.B * a.T * a.Hq * 8, nN = (long long)a.B * a.T * a.Hkv * 8, nR = (long long)a.B * a.Hkv * a.C * 8,
-                  nP = (long long)a.B * a.Hkv * R2_PAD_ROWS * 8;
+  const long long nN = (long long)a.B * a.T * a.Hkv * 8, nR = (long long)a.B * a.Hkv * a.C * 8, nP = (long long)a.B * a.Hkv * R2_PAD_ROWS * 8,
+                  nQ = a.q_rot != nullptr ? (long long)a.B * a.T * a.Hq * 8 : 0;
   const long long plane = (long long)a.B * a.T * SWA_D;
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nQ + nN + nR + nP; idx += (long long)gridDim.x * blockDim.x) {
-    if (idx < nQ) {                                            // (b, t, h, c): rotated q
-      const int c = (int)(idx & 7);
-      int h, t;
-      const long long bt = divmod_idx(idx >> 3, a.Hq, h);
-      const int b = (int)divmod_idx(bt, a.T, t);
-      const bf16_t* src = a.q + (long long)b * a.q_sb + (long long)t * a.q_st + (long long)h * a.q_sh;
-      u32x4 lo = *(const u32x4*)(src + 8 * c), hi = *(const u32x4*)(src + 8 * c + 64);
-      if (a.rcos != nullptr) rope_pair(lo, hi, a.rcos, a.rsin, plane, bt * SWA_D, 8 * c, a.rs0, a.rs1);
-      bf16_t* dst = a.q_rot + (bt * a.Hq + h) * SWA_D;
-      *(u32x4*)(dst + 8 * c) = lo;
-      *(u32x4*)(dst + 8 * c + 64) = hi;
-    } else if (idx < nQ + nN) {                                // (b, t, hk, c): the call's keys / values behind the ring's
-      const long long i2 = idx - nQ;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nN + nR + nP + nQ; idx += (long long)gridDim.x * blockDim.x) {
+    if (idx < nN) {                                            // (b, t, hk, c): the call's keys / values behind the ring's
+      const long long i2 = idx;
       const int c = (int)(i2 & 7);
       int hk, t;
       const long long bt = divmod_idx(i2 >> 3, a.Hkv, hk);
@@ -87,8 +79,8 @@ __global__ __launch_bounds__(256) void swa_linearize_kernel(LinArgs a) {
       *(u32x4*)(a.k_lin + d0 + 8 * c + 64) = hi;
       *(u32x4*)(a.v_lin + d0 + 8 * c) = *(const u32x4*)(a.v_new + so + 8 * c);
       *(u32x4*)(a.v_lin + d0 + 8 * c + 64) = *(const u32x4*)(a.v_new + so + 8 * c + 64);
-    } else if (idx < nQ + nN + nR) {                           // (b, hk, slot, c): ring slot out in chronological order, new token in
-      const long long i2 = idx - nQ - nN;
+    } else if (idx < nN + nR) {                           // (b, hk, slot, c): ring slot out in chronological order, new token in
+      const long long i2 = idx - nN;
       const int c = (int)(i2 & 7);
       int s, hk;
       const long long bh_ = divmod_idx(i2 >> 3, a.C, s);
@@ -111,8 +103,20 @@ __global__ __launch_bounds__(256) void swa_linearize_kernel(LinArgs a) {
         *(u32x4*)(a.v_cache + ro + 8 * c) = v0;
         *(u32x4*)(a.v_cache + ro + 8 * c + 64) = v1;
       }
+    } else if (idx >= nN + nR + nP) {                          // (b, t, h, c): rotated q
+      const long long i2 = idx - nN - nR - nP;
+      const int c = (int)(i2 & 7);
+      int h, t;
+      const long long bt = divmod_idx(i2 >> 3, a.Hq, h);
+      const int b = (int)divmod_idx(bt, a.T, t);
+      const bf16_t* src = a.q + (long long)b * a.q_sb + (long long)t * a.q_st + (long long)h * a.q_sh;
+      u32x4 lo = *(const u32x4*)(src + 8 * c), hi = *(const u32x4*)(src + 8 * c + 64);
+      rope_pair(lo, hi, a.rcos, a.rsin, plane, bt * SWA_D, 8 * c, a.rs0, a.rs1);
+      bf16_t* dst = a.q_rot + (bt * a.Hq + h) * SWA_D;
+      *(u32x4*)(dst + 8 * c) = lo;
+      *(u32x4*)(dst + 8 * c + 64) = hi;
     } else {                                                   // zero rows behind the linear keys
-      const long long i2 = idx - nQ - nN - nR;
+      const long long i2 = idx - nN - nR;
       const int c = (int)(i2 & 7);
       int r;
       const long long bh_ = divmod_idx(i2 >> 3, R2_PAD_ROWS, r);
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256) void swa_linearize_kernel(LinArgs a) {
 }
 
 struct Ring256Params {
-  const bf16_t* q_rot; const bf16_t* k_lin; const bf16_t* v_lin; bf16_t* o;
+  const bf16_t* q; long long q_sb, q_st, q_sh;          // the call's q (UN-rotated when rcos != NULL: rotated below, once per workgroup)
+  const bf16_t* k_lin; const bf16_t* v_lin; bf16_t* o;
   int B, T, Hq, Hkv, C, ntiles, j_hi; long long lin_rows; float sc;
+  const bf16_t* rcos; const bf16_t* rsin; int rs0, rs1;
 };
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void swa_ring256_kernel(Ring256Params p) {
@@ -152,10 +158,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int r_in = lane >> 4, pp = lane & 15;
   const unsigned int k_src = (unsigned int)(r_in * 256 + ((pp ^ ((4 * wave + r_in) & 15)) << 4));
   const unsigned int v_src = (unsigned int)(r_in * 256 + (((((pp >> 2) ^ r_in) << 2) | (pp & 3)) << 4));
-  auto dma_tile = [&](int jt) __attribute__((always_inline)) {
+  auto dma_tile = [&](int jt, int j0, int j1) __attribute__((always_inline)) {
     const unsigned int dst0 = lds_base + (unsigned int)(jt & (R2_NST - 1)) * R2_STAGE + 1024u * wave;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = j0; j < j1; ++j)
 #pragma unroll
       for (int isv = 0; isv < 2; ++isv) {
         const unsigned char* base = uniform_ptr((isv ? vbase : kbase) + (size_t)jt * (R2_KT * 256) + j * 8192);
@@ -165,15 +171,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      : "=&s"(keep) : "v"(isv ? v_src : k_src), "s"(dst), "s"(base) : "memory");
       }
   };
-  dma_tile(0);
-  dma_tile(1 < NT ? 1 : NT - 1);
-  dma_tile(2 < NT ? 2 : NT - 1);
+  dma_tile(0, 0, 2);
+  dma_tile(1, 0, 2);
+  dma_tile(2, 0, 2);
 
   // Q^T fragments (B operand): lane = query row, d = 16 kd + 8 hi .. +7
-  const bf16_t* qrow = p.q_rot + (((long long)b * p.T + r0 + 32 * wave + l31) * p.Hq + h) * SWA_D;
+  const int trow = r0 + 32 * wave + l31;
+  const bf16_t* qrow = p.q + (long long)b * p.q_sb + (long long)trow * p.q_st + (long long)h * p.q_sh;
   u32x4 qf[8];
 #pragma unroll
   for (int kd = 0; kd < 8; ++kd) qf[kd] = *(const u32x4*)(qrow + 16 * kd + 8 * hi5);
+  // fused M-RoPE of the query rows (the 64-apart partner of fragment kd is the lane's own fragment kd + 4): rope_pair's arithmetic,
+  // bit-identical to the pre-pass of the 128-row path; ~700 VALU instructions per lane once per 68-tile workgroup
+  if (p.rcos != nullptr) {
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd)
+      rope_pair(qf[kd], qf[kd + 4], p.rcos, p.rsin, (long long)p.B * p.T * SWA_D, ((long long)b * p.T + trow) * SWA_D, 16 * kd + 8 * hi5, p.rs0, p.rs1);
+  }
   // the compiler's vmcnt bookkeeping must see the Q loads complete BEFORE the loop (it does not model the inline-asm DMA: a
   // pending load at the loop header makes it wait in front of the first MFMAs of every iteration); its wait here also covers the
   // three tiles requested above (older requests)
@@ -301,16 +315,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // rotated half one iteration earlier) passed the barrier that closed iteration t - 1.  At the end of iteration t the wave's own
   // pieces of the tiles <= t + 2 have landed (the four newest requests may fly), so behind the barrier the rotated half may read
   // K(t + 2) in iteration t + 1.  In the last iterations nothing is requested and the wait is for everything.
+  // tile j holds no visible key for ANY row of this wave (band edges only): the wave skips its products and softmax, not the
+  // requests, the wait and the barrier
+  auto vis = [&](int j) __attribute__((always_inline)) {
+    return 64 * j + 63 >= 32 * wave && 64 * j <= 32 * wave + 31 + p.C;
+  };
   auto body = [&](auto rot_tag, auto mask_tag, int t) __attribute__((always_inline)) {
     constexpr bool ROT = decltype(rot_tag)::value;
     constexpr bool MASK = decltype(mask_tag)::value;
-    if (!ROT) qk(t);
-    smax(mask_tag, t);
+    const bool on = !MASK || vis(t);
+    if (on) {
+      if (!ROT) qk(t);
+      smax(mask_tag, t);
+    }
     const bool more = !MASK || t + R2_AHEAD < NT;
-    if (more) dma_tile(t + R2_AHEAD);
-    sexp(mask_tag);
-    pv(t);
-    if (ROT && (!MASK || t + 1 < NT)) qk(t + 1);
+#if !defined(R2_NO_DMA) && R2_DMA_AT == 0
+    if (more) dma_tile(t + R2_AHEAD, 0, 2);
+#elif !defined(R2_NO_DMA) && R2_DMA_AT == 2
+    if (more) dma_tile(t + R2_AHEAD, 0, 1);
+#endif
+    if (on) sexp(mask_tag);
+#if !defined(R2_NO_DMA) && R2_DMA_AT == 1
+    if (more) dma_tile(t + R2_AHEAD, 0, 2);
+#elif !defined(R2_NO_DMA) && R2_DMA_AT == 2
+    if (more) dma_tile(t + R2_AHEAD, 1, 2);
+#endif
+    if (on) pv(t);
+    if (ROT && t + 1 < NT && vis(t + 1)) qk(t + 1);
     if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile_barrier();
@@ -318,18 +349,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto run = [&](auto rot_tag) __attribute__((always_inline)) {
     constexpr bool ROT = decltype(rot_tag)::value;
     if (ROT) {
-      __builtin_amdgcn_s_setprio(1);
-      qk(0);
+#ifdef R2_PRIO      // static priority 1 for the rotated half (what swa_prefill_kernel does) makes THIS kernel 35x slower (5.57 ms
+      __builtin_amdgcn_s_setprio(1);      // vs 157 us per launch, same box): the prio-0 waves also issue the LDS-DMA the others wait for
+#endif
+      if (vis(0)) qk(0);
     }
     const int n_lo = NT < 4 ? NT : 4;
     int t = 0;
     for (; t < n_lo; ++t) body(rot_tag, std::true_type{}, t);
     for (; t < j_hi; ++t) body(rot_tag, std::false_type{}, t);
     for (; t < NT; ++t) body(rot_tag, std::true_type{}, t);
+#ifdef R2_PRIO
     if (ROT) __builtin_amdgcn_s_setprio(0);
+#endif
   };
+#ifdef R2_NO_ROT
+  run(std::false_type{});
+#else
   if (wave < 4) run(std::false_type{});
   else run(std::true_type{});
+#endif
 
   // ---- normalise and store O [B,T,Hq,128]: lane (row l31, half hi5) owns d = 32 mt + 8 qd + 4 hi5 .. +3
   {
@@ -367,7 +406,7 @@ extern "C" size_t ivl_swa_ring256_workspace_bytes(int B, int T, int Hq, int Hkv,
   if (B <= 0 || T <= 0 || Hq <= 0 || Hkv <= 0 || d != SWA_D || cache_capacity < 511) return 0;
   if (T % R2_ROWS != 0 || Hq % Hkv != 0 || (long long)B * Hq * (T / R2_ROWS) < 256) return 0;
   const size_t lin = (size_t)B * Hkv * ((size_t)cache_capacity + T + R2_PAD_ROWS) * SWA_D * sizeof(bf16_t);
-  return (size_t)B * T * Hq * SWA_D * sizeof(bf16_t) + 2 * lin + 256;
+  return 2 * lin + (size_t)B * T * Hq * SWA_D * sizeof(bf16_t) + 256;       // + rotated q
 }
 
 namespace ivl {
@@ -377,24 +416,29 @@ int swa_ring256_launch(const ivl_swa_args* a, hipStream_t st) {
   IVL_REQUIRE(need != 0 && a->workspace != nullptr && a->workspace_bytes >= need, IVL_ERR_WORKSPACE,
               "ivl_swa_fwd(256-row path): workspace %zu bytes < required %zu", a->workspace_bytes, need);
   const long long Lp = (long long)a->cache_capacity + a->T + R2_PAD_ROWS;
-  bf16_t* q_rot = (bf16_t*)(((size_t)a->workspace + 15) & ~(size_t)15);
-  bf16_t* k_lin = q_rot + (size_t)a->B * a->T * a->Hq * SWA_D;
+  bf16_t* k_lin = (bf16_t*)(((size_t)a->workspace + 15) & ~(size_t)15);
   bf16_t* v_lin = k_lin + (size_t)a->B * a->Hkv * Lp * SWA_D;
+  // the query rotation stays in the pre-pass: inside the attention kernel (Ring256Params.rcos) it sits in front of every workgroup's
+  // first product with nothing to overlap it -- +9 us per launch for -7.5 us of pre-pass (same box, in a configs[3] call)
+  bf16_t* q_rot = a->rope_cos != nullptr ? v_lin + (size_t)a->B * a->Hkv * Lp * SWA_D : nullptr;
   LinArgs la;
-  la.q = (const bf16_t*)a->q; la.q_sb = a->q_sb; la.q_st = a->q_st; la.q_sh = a->q_sh;
+  la.q = (const bf16_t*)a->q; la.q_sb = a->q_sb; la.q_st = a->q_st; la.q_sh = a->q_sh; la.q_rot = q_rot; la.Hq = a->Hq;
   la.k_new = (const bf16_t*)a->k_new; la.v_new = (const bf16_t*)a->v_new; la.kn_sb = a->kn_sb; la.kn_st = a->kn_st; la.kn_sh = a->kn_sh;
-  la.k_cache = (bf16_t*)a->k_cache; la.v_cache = (bf16_t*)a->v_cache; la.q_rot = q_rot; la.k_lin = k_lin; la.v_lin = v_lin;
-  la.B = a->B; la.T = a->T; la.Hq = a->Hq; la.Hkv = a->Hkv; la.C = a->cache_capacity; la.pos = a->pos; la.pos_dev = (const long long*)a->pos_dev;
+  la.k_cache = (bf16_t*)a->k_cache; la.v_cache = (bf16_t*)a->v_cache; la.k_lin = k_lin; la.v_lin = v_lin;
+  la.B = a->B; la.T = a->T; la.Hkv = a->Hkv; la.C = a->cache_capacity; la.pos = a->pos; la.pos_dev = (const long long*)a->pos_dev;
   la.rcos = (const bf16_t*)a->rope_cos; la.rsin = (const bf16_t*)a->rope_sin; la.rs0 = a->rope_s0; la.rs1 = a->rope_s1;
   la.append = a->append_new ? 1 : 0;
-  const long long items = ((long long)a->B * a->T * (a->Hq + a->Hkv) + (long long)a->B * a->Hkv * (a->cache_capacity + R2_PAD_ROWS)) * 8;
+  const long long items = ((long long)a->B * a->T * (a->Hkv + (q_rot ? a->Hq : 0)) + (long long)a->B * a->Hkv * (a->cache_capacity + R2_PAD_ROWS)) * 8;
   long long gb = (items + 255) / 256;
   if (gb > 4096) gb = 4096;
   hipLaunchKernelGGL(swa_linearize_kernel, dim3((int)gb), dim3(256), 0, st, la);
   int rc = check_launch("ivl_swa_fwd(linearize pre-pass)");
   if (rc != IVL_OK) return rc;
   Ring256Params p;
-  p.q_rot = q_rot; p.k_lin = k_lin; p.v_lin = v_lin; p.o = (bf16_t*)a->o;
+  p.q = (const bf16_t*)a->q; p.q_sb = a->q_sb; p.q_st = a->q_st; p.q_sh = a->q_sh;
+  p.rcos = nullptr; p.rsin = nullptr; p.rs0 = p.rs1 = 0;
+  if (q_rot != nullptr) { p.q = q_rot; p.q_sb = (long long)a->T * a->Hq * SWA_D; p.q_st = (long long)a->Hq * SWA_D; p.q_sh = SWA_D; }
+  p.k_lin = k_lin; p.v_lin = v_lin; p.o = (bf16_t*)a->o;
   p.B = a->B; p.T = a->T; p.Hq = a->Hq; p.Hkv = a->Hkv; p.C = a->cache_capacity;
   p.ntiles = (R2_ROWS + a->cache_capacity + R2_KT - 1) / R2_KT;
   p.j_hi = (a->cache_capacity + 1) / R2_KT;
