@@ -6,7 +6,12 @@ inside a configs[3] call (100 us)?  (VERDICT r4 #4.)  The launch is timed (profi
   rewritten  : the projection buffer (101 MB) rewritten by a copy kernel in front (what the in-projection GEMM does: the 101 MB
                are dirty in the writing XCDs' L2s at the kernel boundary and come back from the memory side)
   gemm       : the projection written by the real [4096 x 2048] x [2048 x 12320] library GEMM in front
-usage: gdn_incall.py [T=4096] [libpath]"""
+  gemm+idle  : the same GEMM, then ~40 us of an idle spin kernel (torch.cuda._sleep) before the launch: is it the GEMM's write-back
+               still draining when the launch starts (then this equals `evicted`), or where its output ends up?
+  gemm+sweep : the GEMM, then a 256 MB read sweep (the output leaves the L2s / the Infinity Cache clean before the launch)
+usage: gdn_incall.py [T=4096] [libpath|-] [only=<hot|evicted|rewritten|gemm>]
+With `only` (the counter passes of tools/pmc.sh: one predecessor per process, no torch.profiler beside rocprofv3) the launch pair is
+just repeated 12 times."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +20,9 @@ from torch.profiler import ProfilerActivity, profile
 from infinitevl_amd import _lib, ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] != "-":
     _lib.load(sys.argv[2])
+ONLY = sys.argv[3] if len(sys.argv) > 3 else None
 dev = torch.device("cuda", 0)
 B, H, K, V = 1, 16, 128, 256
 Dq, Dk, Dv = H * K, H * K, H * V
@@ -54,7 +60,27 @@ def pre_gemm():
     torch.mm(x, w.t(), out=proj.view(B * T, ld))
 
 
-for name, pre in (("hot", pre_hot), ("evicted", pre_evict), ("rewritten", pre_rewrite), ("gemm", pre_gemm)):
+def pre_gemm_idle():
+    pre_gemm()
+    torch.cuda._sleep(80000)
+
+
+small = torch.empty(1 << 26, dtype=torch.float32, device=dev)        # 256 MB
+
+
+def pre_gemm_sweep():
+    pre_gemm()
+    small.sum()
+
+
+for name, pre in (("hot", pre_hot), ("evicted", pre_evict), ("rewritten", pre_rewrite), ("gemm", pre_gemm), ("gemm+idle", pre_gemm_idle),
+                  ("gemm+sweep", pre_gemm_sweep)):
+    if ONLY is not None:
+        if name == ONLY:
+            for _ in range(12):
+                pre(); gdn()
+            torch.cuda.synchronize()
+        continue
     for _ in range(3):
         pre(); gdn()
     torch.cuda.synchronize()
