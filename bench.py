@@ -89,6 +89,8 @@ def event_time_ms(fn, iters, stream):
     for i in range(3):
         fn(i)
     torch.cuda.synchronize()
+    from infinitevl_amd import ops as _ops
+    _ops.prepare_gdn_capture()             # scope-less capture of (possibly large) GDN chunk calls: their records workspace must exist
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for i in range(iters):

@@ -121,9 +121,9 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  *   workgroups with lower block ids; every wait is bounded; a wait that runs out raises a sticky error word in the area and in
  *   a host-visible status word, and the waiting workgroup stores NO output / state computed from records it has not seen.
  *   After that this entry point returns IVL_ERR_SYNC for every call with THAT sync area (and launches nothing) until
- *   ivl_gdn_sync_reset of the area; calls with other areas -- other streams, other graphs -- go on (an area reports into the
- *   host status slot its address hashes to, 64 slots per device: two areas that share a slot are refused together, which is
- *   one refusal too many, never one too few); workgroups of launches already queued (a hipGraph) stop at once when they find
+ *   ivl_gdn_sync_reset of the area; calls with other areas -- other streams, other graphs -- go on (an area reports into
+ *   its own host status slot: the first 64 distinct area addresses of a device get a slot each; only beyond that do areas share
+ *   slots by address hash and are refused together); workgroups of launches already queued (a hipGraph) stop at once when they find
  *   the area failed.
  * ------------------------------------------------------------------------------------------- */
 #define IVL_GDN_SYNC_BYTES 16384

@@ -1137,8 +1137,8 @@ __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, in
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != want);
     if (bad == 0ull) return true;
     if (bad >> 63) {                                                       // the area has failed before: no use waiting
-      // ... and the host hears of it again: ivl_gdn_sync_reset of ANOTHER area that shares this area's status slot (slots are
-      // assigned by address hash) has cleared the slot while this area is still failed
+      // ... and the host hears of it again: ivl_gdn_sync_reset of ANOTHER area that shares this area's status slot (possible only
+      // beyond 64 registered areas per device: status_slot) has cleared the slot while this area is still failed
       if (lane == 63 && sy.host_err != nullptr) __hip_atomic_store(sy.host_err, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
@@ -2154,13 +2154,33 @@ static void scan_set_attr() {
 static int g_cu_count[64];
 static int g_resident[64][2];                       // [device][F8]: workgroups of the single-launch kernels that can be resident at once
 // [device]: SYNC_STATUS_SLOTS x two words (code, where) of pinned host memory the kernels report a failed wait in.  A sync area
-// reports into the slot its ADDRESS hashes to, so one area's failure refuses further launches on that area (and on the rare area
-// that shares its slot: a refusal too many, never one too few), not on every stream and graph of the device.
+// reports into ITS OWN slot, so one area's failure refuses further launches on that area, not on every stream and graph of the
+// device.  Slots are handed out by registration (with slots assigned by address hash, ivl_gdn_sync_reset of an area B
+// cleared the slot of a still-failed area A that hashed to the same slot, and the next call on A was launched and returned IVL_OK
+// with incomplete outputs): the first SYNC_STATUS_SLOTS distinct area addresses a device sees get a slot each, for the life of the
+// process (an area allocated later at the address of a dead one inherits its slot).  Only a process that uses more than 64
+// distinct area addresses on one device falls back to the hash for the 65th on: those areas may share a slot with another one
+// (refused together: one refusal too many; a reset of one clears the other's report until its workgroups raise it again).
 constexpr int SYNC_STATUS_SLOTS = 64;
 static unsigned int* g_host_status[64];
 static unsigned int* g_host_status_dev[64];         // ... as the device addresses them
+static unsigned long long g_slot_area[64][SYNC_STATUS_SLOTS];      // [device][slot]: the area address that owns the slot (0: free)
+static std::mutex g_slot_mutex;
+static int device_index();
 static inline int status_slot(const void* sync) {
-  return (int)((((unsigned int)((unsigned long long)(size_t)sync >> 8)) * 0x9E3779B1u) >> 26);       // 0 .. 63
+  const unsigned long long a = (unsigned long long)(size_t)sync;
+  unsigned long long* tab = g_slot_area[device_index()];
+  std::lock_guard<std::mutex> lock(g_slot_mutex);
+  int free_slot = -1;
+  for (int s = 0; s < SYNC_STATUS_SLOTS; ++s) {
+    if (tab[s] == a) return s;
+    if (tab[s] == 0ull && free_slot < 0) free_slot = s;
+  }
+  if (free_slot >= 0) {
+    tab[free_slot] = a;
+    return free_slot;
+  }
+  return (int)((((unsigned int)(a >> 8)) * 0x9E3779B1u) >> 26);       // table full: 0 .. 63 by address hash
 }
 static int device_index() {
   int dev = 0;

@@ -30,6 +30,10 @@ __device__ __forceinline__ void store_out16(void* p, u32x4 v) {
 #elif IVL_OUT_STORE == 2
   // (the s_nop: a store of more than 8 bytes reads its data registers after issue, and hipcc does not pad an asm statement --
   //  without it the next instruction may overwrite them first: cdna_hip_programming.md section 5.7)
+  // CONTRACT for callers: hipcc inserts no wait states in FRONT of an asm statement either -- `v` and `p` must be the
+  // results of ordinary VALU instructions (packs, converts, address arithmetic) or of waited loads, never the direct destination
+  // of an MFMA / v_dot or a freshly written SGPR-derived VGPR pair; every caller today passes a pack2bf / cvt_pk result or an LDS
+  // read behind its s_waitcnt.  A new call site that stores an accumulator register as is must copy it through a VALU move first.
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *(u32x4*)p = v;

@@ -357,18 +357,52 @@ def _gdn_workspace(nbytes: int, area: torch.Tensor) -> torch.Tensor:
     return ent[0]
 
 
+_GDN_MIRROR_CAP = 16 << 20     # eager calls up to this size keep the scope-less-capture workspace of the device as large (see below)
+_GDN_EAGER_NEED: Dict[int, int] = {}     # device index -> largest records workspace an eager scope-less call has asked for
+
+
 def _gdn_area_and_workspace(device: torch.device, nbytes: int):
-    """(sync area, records workspace) of a GDN chunk call on the current stream / scope.  An eager call outside any scope also
-    keeps the workspace of the device's area for scope-less CAPTURES at least as large: such a capture is preceded by a warm-up
-    of the same call -- on whatever stream -- and must find its buffers in place (they cannot be created while capturing)."""
+    """(sync area, records workspace) of a GDN chunk call on the current stream / scope.
+
+    Footprint: one records workspace per sync area, i.e. per stream that has issued eager GDN chunk calls and per
+    GraphedStep / gdn_sync_scope owner, each as large as the largest call it has seen (a 4096-token call at B = 1: ~64 MB), for the
+    life of the area -- release_gdn_workspaces() drops the eager ones.  A capture OUTSIDE any scope uses the device's one area for
+    such graphs and must find its workspace in place (nothing can be created while capturing): eager scope-less calls of up to
+    16 MB of records (the step shapes) keep it as large as their own; larger calls only RECORD their need, and whoever captures
+    such a call without a scope calls prepare_gdn_capture() first (bench.py's kernel timings do)."""
     area = _gdn_sync_area(device)
     ws = _gdn_workspace(nbytes, area)
     if not getattr(_GDN_SYNC_SCOPE, "areas", None) and not torch.cuda.is_current_stream_capturing():
         dev = area.device.index
+        _GDN_EAGER_NEED[dev] = max(_GDN_EAGER_NEED.get(dev, 0), int(nbytes))
         garea = _GDN_SYNC.get((dev, "graphs"))
-        if garea is not None and garea is not area:
+        if garea is not None and garea is not area and nbytes <= _GDN_MIRROR_CAP:
             _gdn_workspace(nbytes, garea)
     return area, ws
+
+
+def prepare_gdn_capture(device=None) -> None:
+    """Before capturing GDN chunk calls OUTSIDE a gdn_sync_scope (GraphedStep / GraphedDecode capture inside their own scope and do
+    not need this): size the records workspace of the device's area for scope-less graphs to the largest eager call seen so far
+    (the warm-up of the call that is about to be captured).  No-op when nothing is missing."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    garea = _GDN_SYNC.get((dev, "graphs"))
+    need = _GDN_EAGER_NEED.get(dev, 0)
+    if garea is not None and need > 0:
+        _gdn_workspace(need, garea)
+
+
+def release_gdn_workspaces(device=None) -> None:
+    """Drop the sync areas and records workspaces of EAGER calls on `device` (every stream's; the next eager call creates its own
+    again).  Areas owned by a GraphedStep / a scope live and die with their owner.  Synchronises the device first."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    torch.cuda.synchronize(device)
+    for key in [k for k in _GDN_SYNC if k[0] == dev]:
+        area = _GDN_SYNC.pop(key)
+        _GDN_WS.pop(id(area), None)
+    _GDN_EAGER_NEED.pop(dev, None)
 
 
 def gdn_resident_blocks(override: Optional[int] = None) -> int:

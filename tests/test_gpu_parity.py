@@ -1884,6 +1884,7 @@ def test_gdn_chunk_fused_single_launch_equals_two_launches(B, T, hist, mma, H):
         ops.gdn_chunk_fused(proj, cols, cw, [c.clone() for c in so], [c.clone() for c in so], A32, dt32, H, K, V, initial_state=st.clone(),
                             final_state_out=st.clone())
     torch.cuda.current_stream().wait_stream(side)
+    ops.prepare_gdn_capture()          # a capture outside any gdn_sync_scope: the records workspace of the device's graph area must exist
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         o_static.copy_(ops.gdn_chunk_fused(proj, cols, cw, so, so, A32, dt32, H, K, V, initial_state=st, final_state_out=st))
