@@ -1001,6 +1001,7 @@ def apply_mrope_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin
 
 # the 256-row kernel for long calls over a full ring (swa_ring256.hip); IVL_SWA_RING256=0 keeps every call on the 128-row kernel
 SWA_RING256 = os.environ.get("IVL_SWA_RING256", "1") != "0"
+SWA_RING256_CALLS = 0          # calls that took it (tests read this to know which kernel a product-path call ran on)
 
 
 def swa_forward(
@@ -1048,7 +1049,11 @@ def swa_forward(
             torch.cuda.is_current_stream_capturing() and not pos_min_holds_in_graph):
         pos_min = 0
     else:
-        nbytes = max(nbytes, lib.ivl_swa_ring256_workspace_bytes(B, T, Hq, Hkv, d, C))
+        n256 = lib.ivl_swa_ring256_workspace_bytes(B, T, Hq, Hkv, d, C)      # 0: the shape does not qualify (the launcher decides the same way)
+        if n256 > 0 and mma_code(mma_dtype) == IVL_BF16:
+            global SWA_RING256_CALLS
+            SWA_RING256_CALLS += 1
+        nbytes = max(nbytes, n256)
     ws = get_workspace(nbytes, q.device, "swa")
     a = SwaArgs()
     a.q, a.k_new, a.v_new, a.k_cache, a.v_cache, a.o = (q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),

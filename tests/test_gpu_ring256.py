@@ -152,3 +152,25 @@ def test_ring256_is_not_taken_without_the_callers_bound_or_under_capture():
     assert any("swa_ring256_kernel" in n for n in names(pos_min=seen))
     assert not any("ring256" in n or "linearize" in n for n in names())
     assert not any("ring256" in n or "linearize" in n for n in names(pos_min=W - 2))      # a bound below the capacity is no bound
+
+
+def test_product_path_takes_ring256_on_a_full_ring_and_matches_the_oracle():
+    """Through the MODULES (cache.attend hands the host-side position bound to the operator): one 4-layer period at the model's
+    real width (16 / 2 attention heads, 16 GDN heads), fused path, W = 1024: a 1024-token call fills the ring, then two 4096-token
+    calls run the attention on the 256-row kernel (counted), against the oracle with the reference's rounding points -- the bound
+    of test_full_width_period_vs_oracle (2.5e-2 at this width, where bf16 rounding alone moves a 4-layer output by ~1.7e-2) -- and
+    the ring / GDN state at the end."""
+    import parity
+    from infinitevl_amd import ops
+    before = ops.SWA_RING256_CALLS
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 16))        # the oracle's many small operators collapse on a many-core host's default thread count
+    try:
+        r = parity.layer_parity(DEV, window=1024, seed=11, fuse=True, heads=16, schedule=[1024, 4096, 4096])
+    finally:
+        torch.set_num_threads(nthr)
+    print("ring256 through the modules:", {k: round(v, 5) for k, v in r.items()})
+    assert ops.SWA_RING256_CALLS - before == 2, ops.SWA_RING256_CALLS - before
+    for name in ("call0", "call1", "call2"):
+        assert r[name] < 2.5e-2, r
+    assert r["swa_keys"] < 6e-3 and r["gdn_state"] < 1.2e-2, r
