@@ -979,6 +979,9 @@ def main():
                 hit = [v for k, v in by3.items() if any(k.startswith(p_) for p_ in prefixes)]
                 return (sum(v["avg_us"] * v["launches"] for v in hit), max(v["launches"] for v in hit)) if hit else (None, 0)
             for key, prefixes in (("gdn_chunk_fused@T=4096", ("gdn_chunk_single_kernel", "gdn_chunk_prepare_kernel", "gdn_chunk_scan_kernel")),
+                                  # (the configs[3] calls over a full ring run the 256-row kernel since round 6; with IVL_SWA_RING256=0 the
+                                  #  128-row entry gets the in-call figure instead)
+                                  ("swa_ring256@T=4096(full ring, rope + append)", ("swa_linearize_kernel", "swa_ring256_kernel")),
                                   ("swa_prefill@T=4096(full ring, rope + append)", ("swa_rope_prepass_kernel", "swa_prefill_kernel",
                                                                                      "swa_cache_append_kernel", "swa_combine_kernel"))):
                 tot, nl = in_call(prefixes)
