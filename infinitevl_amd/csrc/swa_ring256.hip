@@ -443,10 +443,12 @@ int swa_ring256_launch(const ivl_swa_args* a, hipStream_t st) {
   p.ntiles = (R2_ROWS + a->cache_capacity + R2_KT - 1) / R2_KT;
   p.j_hi = (a->cache_capacity + 1) / R2_KT;
   p.lin_rows = Lp; p.sc = a->scaling * LOG2E;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64];                       // per device: a function attribute belongs to the device's copy of the code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!__atomic_load_n(&attr_set[dev & 63], __ATOMIC_ACQUIRE)) {
     (void)hipFuncSetAttribute((const void*)swa_ring256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS);
-    attr_set = true;
+    __atomic_store_n(&attr_set[dev & 63], true, __ATOMIC_RELEASE);
   }
   hipLaunchKernelGGL(swa_ring256_kernel, dim3(a->B * a->Hq * (a->T / R2_ROWS)), dim3(512), R2_LDS, st, p);
   return check_launch("ivl_swa_fwd(256-row attention)");
