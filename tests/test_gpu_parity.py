@@ -2011,14 +2011,23 @@ def test_gdn_single_launch_reports_a_wait_that_runs_out(T, chunk):
             assert ei.value.code == IVL_ERR_SYNC and "head 2" in str(ei.value)
             with pytest.raises(IvlError):
                 run(True)                                          # refused: nothing is launched on a failed area
-            # ... while ANOTHER area (another stream's, another graph's) goes on: an area reports into the status slot its address
-            # hashes to (csrc/gdn_chunk.hip status_slot, mirrored here to pick an area that does not share the failed one's)
-            slot = lambda a: (((a.data_ptr() >> 8) & 0xffffffff) * 0x9E3779B1 & 0xffffffff) >> 26      # noqa: E731
-            other = next(a for a in [ops.new_gdn_sync_area(DEV) for _ in range(6)] if slot(a) != slot(area))
-            with ops.gdn_sync_scope(other):
+            # ... while ANOTHER area (another stream's, another graph's) goes on: every area reports into a status slot of its own
+            # (csrc/gdn_chunk.hip status_slot: handed out by registration since round 6)
+            others = [ops.new_gdn_sync_area(DEV) for _ in range(24)]
+            with ops.gdn_sync_scope(others[0]):
                 ob = run(True)
                 torch.cuda.synchronize()
                 assert torch.equal(ob[0], ref[0]) and torch.equal(ob[1], ref[1])
+            # re-arming OTHER areas (here 24 of them, one by one through the C entry point) must not clear the failed
+            # area's report -- with slots assigned by address hash one of them could share its slot, and the next call on the failed
+            # area was then launched and returned IVL_OK with incomplete outputs
+            lib = ops._lib.load()
+            for a in others:
+                ops._lib.check(lib.ivl_gdn_sync_reset(a.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            with pytest.raises(IvlError) as ei2:
+                ops.gdn_sync_check(DEV)
+            assert ei2.value.code == IVL_ERR_SYNC
             with pytest.raises(IvlError):
                 run(True)                                          # the failed area is still refused
             ops.gdn_sync_reset(DEV)
@@ -2749,3 +2758,37 @@ def test_decode_tokens_with_the_split_step_equal_the_one_launch_step():
             assert torch.equal(a.recurrent_state, b_.recurrent_state)
             for nm in ("conv_state_q", "conv_state_k", "conv_state_v"):
                 assert torch.equal(getattr(a, nm), getattr(b_, nm)), nm
+
+
+def test_gdn_workspace_mirror_is_capped_and_prepare_release_work():
+    """an eager scope-less call no longer grows the records workspace of the device's area for scope-less CAPTURES beyond
+    16 MB (a 4096-token call is ~64 MB: plain eager use held it twice); `ops.prepare_gdn_capture()` sizes it on request (the capture
+    then works and replays bit-identically), `ops.release_gdn_workspaces()` drops the eager areas and buffers, and the next eager
+    call builds its own again."""
+    from infinitevl_amd import ops
+    run = _gdn_fused_case(4096)
+    torch.cuda.synchronize()
+    ops.release_gdn_workspaces(DEV)
+    dev = torch.device(DEV).index
+    assert not [k for k in ops._GDN_SYNC if k[0] == dev]
+    ref = run(True)                                                  # eager, single launch, ~64 MB of records
+    torch.cuda.synchronize()
+    garea = ops._GDN_SYNC[(dev, "graphs")]
+    ent = ops._GDN_WS.get(id(garea))
+    assert ent is None or ent[0].numel() <= ops._GDN_MIRROR_CAP, "the mirror must not follow a large eager call"
+    eager_area = ops._gdn_sync_area(torch.device(DEV))
+    assert ops._GDN_WS[id(eager_area)][0].numel() >= 60 << 20
+    ops.prepare_gdn_capture(DEV)                                     # (without it the capture below would have to grow the buffer: refused)
+    assert ops._GDN_WS[id(garea)][0].numel() >= 60 << 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run(True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    del g, out
+    ops.release_gdn_workspaces(DEV)
+    assert not [k for k in ops._GDN_SYNC if k[0] == dev] and id(garea) not in ops._GDN_WS
+    again = run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(again[0], ref[0])
