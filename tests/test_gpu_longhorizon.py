@@ -149,6 +149,34 @@ def test_stream_131k_tokens_headline_geometry_vs_oracle():
     _check_stream(at, per_step, n, T, W, h_bound=1.5e-2)
 
 
+def test_stream_12k_tokens_at_the_models_real_width_vs_oracle():
+    """The same stream at the model's REAL width (hidden 2048, 16 GDN heads = all eight column slabs of the scan, 16 / 2 attention
+    heads = the packed-GQA shapes), 48 x 256 tokens over a 1024-key window (12 ring revolutions), one captured graph, against the
+    oracle's reference-rounding model AND its exact fp32 run.  At this width bf16 rounding alone moves a 4-layer output by ~2e-2
+    (test_full_width_period_vs_oracle), and the conv / recurrent states of the deeper layers inherit the noise of the hidden states
+    they are computed from -- so every bound here is stated against the distance the reference-rounding model itself keeps from the
+    exact run; what this test adds is that the relation HOLDS, flat, over 48 replays."""
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 32))          # real-width GEMMs: more host threads than the 2-head tests
+    try:
+        n, T, W = 48, 256, 1024
+        at, per_step = _stream_stack(n, T, W, checkpoints={1, 4, 5, 16, 32, 48}, heads=16)
+    finally:
+        torch.set_num_threads(min(nthr, 8))
+    for step, r in sorted(at.items()):
+        print(f"  real width, step {step:3d}: hidden hip-model {r['h_vs_model']:.2e} hip-exact {r['h_vs_exact']:.2e} model-exact {r['model_vs_exact']:.2e} | "
+              f"state hip-model {r['state_vs_model']:.2e} hip-exact {r['state_vs_exact']:.2e} model-exact {r['state_model_vs_exact']:.2e} | "
+              f"conv {r['conv_vs_model']:.1e} ring k {r['ring_keys']:.2e} v {r['ring_values']:.2e}")
+        assert r["finite"] and r["pos_dev"] == step * T and r["size"][0] == r["size"][1] == min(W - 1, step * T), (step, r)
+        assert r["h_vs_model"] < 2.5e-2 and r["h_vs_exact"] < 1.25 * r["model_vs_exact"] + 1e-3, (step, r)
+        assert r["state_vs_exact"] < 1.5 * r["state_model_vs_exact"] + 1e-3 and r["state_vs_model"] < 4e-2, (step, r)
+        assert r["ring_keys"] < 6e-3 and r["ring_values"] < 6e-3 and r["conv_vs_model"] < 2.5e-2, (step, r)   # ring: layer 0 (identical inputs)
+    early = max(e[0] for e in per_step[12:24])
+    late = max(e[0] for e in per_step[-12:])
+    print(f"  hidden hip-model, worst of steps 13-24: {early:.3e}; of the last 12: {late:.3e}")
+    assert late < 1.25 * early + 1e-3, (early, late)
+
+
 def _decay_mix(seed: int, T: int, H: int):
     """One call's operator inputs.  Per-head decay scales 1, 1e-1, 1e-2, 1e-3 (x fla's logsigmoid(randn) log-decay):
     memory horizons from a few tokens to ~1,500 tokens = six 256-token calls, so the bf16 rounding of the CARRIED state

@@ -254,3 +254,21 @@ def test_ring256_is_bit_stable_across_repeats_beside_a_co_running_stream():
             first = (o.clone(), kc.clone(), vc.clone())
         else:
             assert torch.equal(o, first[0]) and torch.equal(kc, first[1]) and torch.equal(vc, first[2]), rep
+
+
+def test_configs1_shape_one_period_at_real_width_vs_oracle():
+    """BASELINE configs[1]'s call shapes on ONE 4-layer period at the model's real width against the ORACLE (the 36-layer test of
+    test_gpu_parity.py compares the HIP path with itself): a 4096-token prefill in one call on a fresh cache (causal 128-row attention
+    behind the rope pre-pass, the long-call GDN launch), then three decode tokens (recurrent step, packed-GQA decode attention over the
+    ring), W = 4096."""
+    import parity
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 16))
+    try:
+        r = parity.layer_parity(DEV, window=4096, seed=13, fuse=True, heads=16, schedule=[4096, 1, 1, 1])
+    finally:
+        torch.set_num_threads(nthr)
+    print("configs[1] shapes, one period at real width:", {k: round(v, 5) for k, v in r.items()})
+    for name in ("call0", "call1", "call2", "call3"):
+        assert r[name] < 2.5e-2, r
+    assert r["swa_keys"] < 6e-3 and r["gdn_state"] < 1.2e-2, r
