@@ -15,9 +15,9 @@
 //      the lower band edge, tiles >= (C + 1) / 64 the upper one: they run a body with the band test; all tiles between are
 //      interior for every row and run a body WITHOUT any mask or tile-kind code.  K / V tiles: unpadded 64 x 256 B images,
 //      XOR-swizzled on the source side of the LDS-DMA (K 16-byte piece p of row r at p ^ (r & 15), V 64-byte granule g at
-//      g ^ (r & 3)), 4 one-KB pieces per wave and tile issued by the compute waves between the row maximum and the exponentials,
-//      a 4-stage ring filled three tiles ahead, one barrier per tile; waves 4-7 (the SIMD partners of 0-3) run their phases
-//      rotated by one (softmax(t), PV(t), QK^T(t + 1)) at static priority 1.
+//      g ^ (r & 3)), 32 one-KB pieces per tile issued by the compute waves 0-3 (eight each) between their row maximum and their
+//      exponentials, a 4-stage ring filled three tiles ahead, one barrier per tile; waves 4-7 (the SIMD partners of 0-3) request
+//      nothing and run their phases rotated by one (softmax(t), PV(t), QK^T(t + 1)); no static priority (it costs 3-35 x here).
 #include "ivl_common.h"
 #include "swa_shared.h"
 #include <type_traits>
@@ -30,6 +30,10 @@ constexpr int R2_STAGE = 2 * R2_KT * 256;    // K image + V image = 32 KB
 constexpr int R2_NST = 4;                    // stages
 constexpr int R2_AHEAD = 3;                  // tiles requested ahead
 constexpr int R2_LDS = R2_NST * R2_STAGE;    // 128 KB
+#ifndef R2_DMA_BY
+#define R2_DMA_BY 2                          // who requests the tiles of the loop: 0 every wave four pieces per tile; 1 / 2 only waves
+                                             // 4-7 / 0-3, eight each (2 = default: -3 ... -6 % against 0 on three boxes; 1: +1.5 %)
+#endif
 #ifndef R2_DMA_AT
 #define R2_DMA_AT 0                          // where the four DMA pieces of a tile are issued: 0 behind the row maximum, 1 behind the
 #endif                                       // exponentials, 2 two and two
@@ -171,6 +175,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                      : "=&s"(keep) : "v"(isv ? v_src : k_src), "s"(dst), "s"(base) : "memory");
       }
   };
+#if R2_DMA_BY
+  // role split: only one half of the waves (R2_DMA_BY 1: the rotated half 4-7, 2: waves 0-3) requests the tiles of the loop, eight pieces
+  // per wave and tile: wave w' = wave & 3 moves chunks w', w' + 4, w' + 8, w' + 12 of both images
+  const bool dma_role = R2_DMA_BY == 1 ? wave >= 4 : wave < 4;       // (3: as 2, the K pieces behind the row maximum, the V pieces behind the exponentials)
+  const unsigned int k_src8 = (unsigned int)(r_in * 256 + ((pp ^ ((4 * (wave & 3) + r_in) & 15)) << 4));
+  auto dma_tile8 = [&](int jt, int v0 = 0, int v1 = 2) __attribute__((always_inline)) {
+    const unsigned int dst0 = lds_base + (unsigned int)(jt & (R2_NST - 1)) * R2_STAGE + 1024u * (wave & 3);
+    const size_t wofs = (size_t)jt * (R2_KT * 256) + (size_t)(wave & 3) * 1024 - (size_t)wave * 1024;     // kbase / vbase carry wave * 1024
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int isv = v0; isv < v1; ++isv) {
+        const unsigned char* base = uniform_ptr((isv ? vbase : kbase) + wofs + j * 4096);
+        const unsigned int dst = __builtin_amdgcn_readfirstlane(dst0 + (isv ? 16384u : 0u) + 4096u * j);
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(isv ? v_src : k_src8), "s"(dst), "s"(base) : "memory");
+      }
+  };
+#endif
   dma_tile(0, 0, 2);
   dma_tile(1, 0, 2);
   dma_tile(2, 0, 2);
@@ -329,12 +353,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       smax(mask_tag, t);
     }
     const bool more = !MASK || t + R2_AHEAD < NT;
-#if !defined(R2_NO_DMA) && R2_DMA_AT == 0
+#if R2_DMA_BY == 3
+    if (more && dma_role) dma_tile8(t + R2_AHEAD, 0, 1);
+#elif R2_DMA_BY
+    if (more && dma_role) dma_tile8(t + R2_AHEAD);
+#elif !defined(R2_NO_DMA) && R2_DMA_AT == 0
     if (more) dma_tile(t + R2_AHEAD, 0, 2);
 #elif !defined(R2_NO_DMA) && R2_DMA_AT == 2
     if (more) dma_tile(t + R2_AHEAD, 0, 1);
 #endif
     if (on) sexp(mask_tag);
+#if R2_DMA_BY == 3
+    if (more && dma_role) dma_tile8(t + R2_AHEAD, 1, 2);
+#endif
 #if !defined(R2_NO_DMA) && R2_DMA_AT == 1
     if (more) dma_tile(t + R2_AHEAD, 0, 2);
 #elif !defined(R2_NO_DMA) && R2_DMA_AT == 2
@@ -342,8 +373,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     if (on) pv(t);
     if (ROT && t + 1 < NT && vis(t + 1)) qk(t + 1);
+#if R2_DMA_BY
+    if (more && dma_role) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     tile_barrier();
   };
   auto run = [&](auto rot_tag) __attribute__((always_inline)) {
@@ -354,6 +390,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
       if (vis(0)) qk(0);
     }
+#ifdef R2_PRIO0
+    if (!ROT) __builtin_amdgcn_s_setprio(1);
+#endif
     const int n_lo = NT < 4 ? NT : 4;
     int t = 0;
     for (; t < n_lo; ++t) body(rot_tag, std::true_type{}, t);
@@ -361,6 +400,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (; t < NT; ++t) body(rot_tag, std::true_type{}, t);
 #ifdef R2_PRIO
     if (ROT) __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef R2_PRIO0
+    if (!ROT) __builtin_amdgcn_s_setprio(0);
 #endif
   };
 #ifdef R2_NO_ROT
