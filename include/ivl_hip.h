@@ -122,8 +122,8 @@ IVL_API int ivl_gdn_chunk_fwd(const void* q, const void* k, const void* v, const
  *   a host-visible status word, and the waiting workgroup stores NO output / state computed from records it has not seen.
  *   After that this entry point returns IVL_ERR_SYNC for every call with THAT sync area (and launches nothing) until
  *   ivl_gdn_sync_reset of the area; calls with other areas -- other streams, other graphs -- go on (an area reports into
- *   its own host status slot: the first 64 distinct area addresses of a device get a slot each; only beyond that do areas share
- *   slots by address hash and are refused together); workgroups of launches already queued (a hipGraph) stop at once when they find
+ *   its own host status slot: the 64 most recently used area addresses of a device own a slot each, and a failed area never loses
+ *   its slot); workgroups of launches already queued (a hipGraph) stop at once when they find
  *   the area failed.
  * ------------------------------------------------------------------------------------------- */
 #define IVL_GDN_SYNC_BYTES 16384

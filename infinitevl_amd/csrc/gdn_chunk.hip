@@ -1137,8 +1137,8 @@ __device__ __forceinline__ bool scan_wait_records(const ScanSync& sy, int bh, in
     const unsigned long long bad = __builtin_amdgcn_ballot_w64(v != want);
     if (bad == 0ull) return true;
     if (bad >> 63) {                                                       // the area has failed before: no use waiting
-      // ... and the host hears of it again: ivl_gdn_sync_reset of ANOTHER area that shares this area's status slot (possible only
-      // beyond 64 registered areas per device: status_slot) has cleared the slot while this area is still failed
+      // ... and the host hears of it again: should ANOTHER area ever share this area's status slot (status_slot: only when all 64
+      // slots hold failed areas), its reset has cleared the slot while this area is still failed
       if (lane == 63 && sy.host_err != nullptr) __hip_atomic_store(sy.host_err, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
@@ -2157,30 +2157,45 @@ static int g_resident[64][2];                       // [device][F8]: workgroups 
 // reports into ITS OWN slot, so one area's failure refuses further launches on that area, not on every stream and graph of the
 // device.  Slots are handed out by registration (with slots assigned by address hash, ivl_gdn_sync_reset of an area B
 // cleared the slot of a still-failed area A that hashed to the same slot, and the next call on A was launched and returned IVL_OK
-// with incomplete outputs): the first SYNC_STATUS_SLOTS distinct area addresses a device sees get a slot each, for the life of the
-// process (an area allocated later at the address of a dead one inherits its slot).  Only a process that uses more than 64
-// distinct area addresses on one device falls back to the hash for the 65th on: those areas may share a slot with another one
-// (refused together: one refusal too many; a reset of one clears the other's report until its workgroups raise it again).
+// with incomplete outputs): an area address keeps its slot while it is among the 64 most recently used ones of its device; when
+// all slots are taken, a new address takes over the least recently used slot whose status is HEALTHY (a failed area never loses
+// its slot; an area that lost a healthy slot simply registers again at its next call).  Only if all 64 slots hold failed areas
+// does an address fall back to the hash (shared slot: refused together with its owner).
 constexpr int SYNC_STATUS_SLOTS = 64;
 static unsigned int* g_host_status[64];
 static unsigned int* g_host_status_dev[64];         // ... as the device addresses them
 static unsigned long long g_slot_area[64][SYNC_STATUS_SLOTS];      // [device][slot]: the area address that owns the slot (0: free)
+static unsigned long long g_slot_used[64][SYNC_STATUS_SLOTS];      // ... and when it was last looked up (a per-process counter)
+static unsigned long long g_slot_clock = 0;
 static std::mutex g_slot_mutex;
 static int device_index();
 static inline int status_slot(const void* sync) {
   const unsigned long long a = (unsigned long long)(size_t)sync;
-  unsigned long long* tab = g_slot_area[device_index()];
+  const int dev = device_index();
+  unsigned long long* tab = g_slot_area[dev];
+  unsigned long long* used = g_slot_used[dev];
+  const unsigned int* hs = g_host_status[dev];
   std::lock_guard<std::mutex> lock(g_slot_mutex);
-  int free_slot = -1;
+  const unsigned long long now = ++g_slot_clock;
+  int free_slot = -1, lru = -1;
   for (int s = 0; s < SYNC_STATUS_SLOTS; ++s) {
-    if (tab[s] == a) return s;
-    if (tab[s] == 0ull && free_slot < 0) free_slot = s;
+    if (tab[s] == a) {
+      used[s] = now;
+      return s;
+    }
+    if (tab[s] == 0ull) {
+      if (free_slot < 0) free_slot = s;
+    } else if ((hs == nullptr || __atomic_load_n(hs + 2 * s, __ATOMIC_RELAXED) == 0u) && (lru < 0 || used[s] < used[lru])) {
+      lru = s;
+    }
   }
-  if (free_slot >= 0) {
-    tab[free_slot] = a;
-    return free_slot;
+  const int take = free_slot >= 0 ? free_slot : lru;
+  if (take >= 0) {
+    tab[take] = a;
+    used[take] = now;
+    return take;
   }
-  return (int)((((unsigned int)(a >> 8)) * 0x9E3779B1u) >> 26);       // table full: 0 .. 63 by address hash
+  return (int)((((unsigned int)(a >> 8)) * 0x9E3779B1u) >> 26);       // every slot holds a failed area: 0 .. 63 by address hash
 }
 static int device_index() {
   int dev = 0;
