@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned int k_src8 = (unsigned int)(r_in * 256 + ((pp ^ ((4 * (wave & 3) + r_in) & 15)) << 4));
   auto dma_tile8 = [&](int jt, int v0 = 0, int v1 = 2) __attribute__((always_inline)) {
     const unsigned int dst0 = lds_base + (unsigned int)(jt & (R2_NST - 1)) * R2_STAGE + 1024u * (wave & 3);
-    const size_t wofs = (size_t)jt * (R2_KT * 256) + (size_t)(wave & 3) * 1024 - (size_t)wave * 1024;     // kbase / vbase carry wave * 1024
+    const long long wofs = (long long)jt * (R2_KT * 256) + ((wave & 3) - wave) * 1024;      // kbase / vbase carry wave * 1024
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
