@@ -101,6 +101,14 @@ def test_workspace_sizes(lib):
     assert lib.ivl_gdn_chunk_workspace_bytes(1, 256, 16, 64, 256) == 0
     assert lib.ivl_swa_workspace_bytes(1, 4096, 16, 128) <= (1 << 20) * 600
     assert lib.ivl_swa_workspace_bytes(1, 1, 16, 64) == 0
+    # the 256-row attention path (ABI v11): rotated q + two linear copies [B, Hkv, C + T + 64, 128] bf16 (+ 256 B); 0 = the shape
+    # does not qualify (T not a multiple of 256, fewer than 256 workgroups of 256 rows, a small ring, another head size)
+    lin = 2 * (4095 + 4096 + 64) * 128 * 2
+    assert lib.ivl_swa_ring256_workspace_bytes(1, 4096, 16, 2, 128, 4095) == 2 * lin + 4096 * 16 * 128 * 2 + 256
+    assert lib.ivl_swa_ring256_workspace_bytes(8, 512, 16, 2, 128, 511) > 0
+    for bad in ((1, 4000, 16, 2, 128, 4095), (1, 2048, 16, 2, 128, 4095), (1, 4096, 16, 2, 128, 300), (1, 4096, 16, 2, 64, 4095),
+                (1, 4096, 16, 3, 128, 4095), (0, 4096, 16, 2, 128, 4095)):
+        assert lib.ivl_swa_ring256_workspace_bytes(*bad) == 0, bad
 
 
 def test_ops_refuse_cpu_tensors():
