@@ -149,6 +149,16 @@ def test_stream_131k_tokens_headline_geometry_vs_oracle():
     _check_stream(at, per_step, n, T, W, h_bound=1.5e-2)
 
 
+@pytest.mark.skipif(__import__("os").environ.get("IVL_LONG_1M", "0") != "1", reason="opt-in (IVL_LONG_1M=1): ~3 minutes of oracle time")
+def test_stream_1m_tokens_vs_oracle():
+    """BASELINE.json configs[4]'s length: a continuous 1,048,576-token stream (4096 x 256-token replays of ONE graph, W = 4096: 256
+    ring revolutions, 4096 bf16 roundings of every recurrent state) on the small-heads stack against the oracle's reference-rounding
+    model over the whole length.  Opt-in; the result of the round-6 run is in profiles/r06_long_horizon.txt."""
+    n, T, W = 4096, 256, 4096
+    at, per_step = _stream_stack(n, T, W, checkpoints={1, 64, 512, 1024, 2048, 3072, 4096}, exact=False)
+    _check_stream(at, per_step, n, T, W, h_bound=1.5e-2, exact=False)
+
+
 def test_stream_12k_tokens_at_the_models_real_width_vs_oracle():
     """The same stream at the model's REAL width (hidden 2048, 16 GDN heads = all eight column slabs of the scan, 16 / 2 attention
     heads = the packed-GQA shapes), 48 x 256 tokens over a 1024-key window (12 ring revolutions), one captured graph, against the
